@@ -1,0 +1,187 @@
+/*
+ * mgar_ops.h -- C ABI of libmgar_hip.so, the MI355X (gfx950) implementation of the
+ * MGAR-net hot-path operators.
+ *
+ * This is the drop-in boundary: every entry point below replaces one function of the
+ * reference's pybind11 tables (file:line cited per function, relative to
+ * /root/reference/) or one third-party op the reference calls on the hot path.
+ * INTEGRATION.md shows the reference-side binding for each.
+ *
+ * Conventions:
+ *   - plain C, raw DEVICE pointers + sizes, no torch / hip types in the signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the default stream);
+ *   - the CALLER allocates every output and scratch buffer, exactly as the reference's
+ *     Python wrappers do; the library allocates nothing, keeps nothing, never
+ *     synchronises the host, and is re-entrant;
+ *   - buffers are contiguous float32 / int32 on the device the stream belongs to;
+ *   - return value: 0 on success, a negative MGAR_E* code otherwise.  The reference
+ *     prints and exit(-1)s on failure (e.g. pointnet2_batch/src/ball_query_gpu.cu:68-72);
+ *     this library never exits the process.
+ */
+#ifndef MGAR_OPS_H
+#define MGAR_OPS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGAR_OK 0
+#define MGAR_EINVAL (-1)      /* null pointer / negative size / inconsistent arguments      */
+#define MGAR_ELAUNCH (-2)     /* hipGetLastError() != hipSuccess after the launch            */
+#define MGAR_EUNSUPPORTED (-3)/* size outside what the kernel was built for (e.g. nsample)   */
+
+#define MGAR_MAX_NSAMPLE 128   /* ball/voxel query: rows are staged in LDS                   */
+
+/* Library identity: ABI version (bumped on any signature change) and a static
+ * description string of the last error on the calling thread. */
+int mgar_abi_version(void);
+const char *mgar_last_error(void);
+
+/* ======================= pointnet2_batch: (B, N, 3) / (B, C, N) ======================= */
+
+/* ball_query_wrapper   pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:11
+ * kernel               pointnet2_batch/src/ball_query_gpu.cu:15-51
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample).  First nsample indices k (ascending)
+ * with d2 < radius^2, row padded with the first hit; rows of empty balls are NOT written
+ * (the caller zero-fills idx, pointnet2_batch/pointnet2_utils.py:218). */
+int mgar_ball_query_batch(int b, int n, int m, float radius, int nsample,
+                          const float *new_xyz, const float *xyz, int *idx, void *stream);
+
+/* group_points_wrapper / group_points_grad_wrapper   pointnet2_api.cpp:13-14
+ * kernels              pointnet2_batch/src/group_points_gpu.cu:53-72, :14-31
+ * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample);
+ * grad: grad_out (b,c,npoints,nsample) accumulated into caller-zeroed grad_points (b,c,n). */
+int mgar_group_points_batch(int b, int c, int n, int npoints, int nsample,
+                            const float *points, const int *idx, float *out, void *stream);
+int mgar_group_points_grad_batch(int b, int c, int n, int npoints, int nsample,
+                                 const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* gather_points_wrapper / gather_points_grad_wrapper   pointnet2_api.cpp:16-17
+ * kernels              pointnet2_batch/src/sampling_gpu.cu:15-31, :53-70 */
+int mgar_gather_points_batch(int b, int c, int n, int npoints,
+                             const float *points, const int *idx, float *out, void *stream);
+int mgar_gather_points_grad_batch(int b, int c, int n, int npoints,
+                                  const float *grad_out, const int *idx, float *grad_points, void *stream);
+
+/* farthest_point_sampling_wrapper   pointnet2_api.cpp:19
+ * kernel               pointnet2_batch/src/sampling_gpu.cu:101-216 (launcher :218-259)
+ * points (b,n,3), temp (b,n) pre-filled by the caller (1e10) -> idx (b,m).
+ * temp is updated in place to the final min-distances, like the reference.
+ * Ties are resolved exactly as the reference's block_size = min(2^floor(log2 n),1024)
+ * strided scan + shared-memory tree would (FPS tie rule). */
+int mgar_fps_batch(int b, int n, int m, const float *points, float *temp, int *idx, void *stream);
+
+/* three_nn_wrapper   pointnet2_api.cpp:21;  kernel interpolate_gpu.cu:16-59
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3). */
+int mgar_three_nn_batch(int b, int n, int m, const float *unknown, const float *known,
+                        float *dist2, int *idx, void *stream);
+
+/* three_interpolate_wrapper / _grad_wrapper   pointnet2_api.cpp:22-23
+ * kernels              pointnet2_batch/src/interpolate_gpu.cu:84-104, :127-149
+ * points (b,c,m), idx/weight (b,n,3) -> out (b,c,n); grad accumulates into grad_points (b,c,m). */
+int mgar_three_interpolate_batch(int b, int c, int m, int n, const float *points, const int *idx,
+                                 const float *weight, float *out, void *stream);
+int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                      const float *weight, float *grad_points, void *stream);
+
+/* ============== pointnet2_stack: (N1+N2+..., 3|C) + per-sample counts ================= */
+
+/* ball_query_wrapper   pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:13
+ * kernel               pointnet2_stack/src/ball_query_gpu.cu:16-66
+ * As the batch version, local indices; an empty ball writes idx[row][0] = -1 only. */
+int mgar_ball_query_stack(int B, int M, float radius, int nsample,
+                          const float *new_xyz, const int *new_xyz_batch_cnt,
+                          const float *xyz, const int *xyz_batch_cnt, int *idx, void *stream);
+
+/* voxel_query_wrapper   pointnet2_stack/src/pointnet2_api.cpp:14
+ * kernel               pointnet2_stack/src/voxel_query_gpu.cu:10-89
+ * new_coords (M,4) [b,z,y,x]; point_indices (B,R1,R2,R3) of global row ids or -1.
+ * Cells are visited dz,dy,dx ascending; accept d2 <= radius^2; idx[row][0] = -1 if none. */
+int mgar_voxel_query_stack(int M, int R1, int R2, int R3, int nsample, float radius,
+                           int z_range, int y_range, int x_range,
+                           const float *new_xyz, const float *xyz, const int *new_coords,
+                           const int *point_indices, int *idx, void *stream);
+
+/* stack_farthest_point_sampling_wrapper   pointnet2_stack/src/pointnet2_api.cpp:17
+ * kernel               pointnet2_stack/src/sampling_gpu.cu:188-319 (always 1024 threads)
+ * points (N,3), temp (N), xyz_batch_cnt (batch_size), num_sampled_points (batch_size)
+ * -> idx (sum m_i) GLOBAL row ids. */
+int mgar_fps_stack(int batch_size, int N, const float *points, float *temp, const int *xyz_batch_cnt,
+                   int *idx, const int *num_sampled_points, void *stream);
+
+/* group_points_wrapper / group_points_grad_wrapper   pointnet2_stack/src/pointnet2_api.cpp:19-20
+ * kernels              pointnet2_stack/src/group_points_gpu.cu:71-102, :15-45
+ * features (N,C) row-major, idx (M,nsample) local -> out (M,C,nsample). */
+int mgar_group_points_stack(int B, int M, int C, int nsample, const float *features,
+                            const int *features_batch_cnt, const int *idx, const int *idx_batch_cnt,
+                            float *out, void *stream);
+int mgar_group_points_grad_stack(int B, int M, int C, int N, int nsample, const float *grad_out,
+                                 const int *idx, const int *idx_batch_cnt, const int *features_batch_cnt,
+                                 float *grad_features, void *stream);
+
+/* three_nn_wrapper   pointnet2_stack/src/pointnet2_api.cpp:22; kernel interpolate_gpu.cu:16-75
+ * idx are GLOBAL rows of `known`. */
+int mgar_three_nn_stack(int batch_size, int N, int M, const float *unknown, const int *unknown_batch_cnt,
+                        const float *known, const int *known_batch_cnt, float *dist2, int *idx, void *stream);
+
+/* three_interpolate_wrapper / _grad_wrapper   pointnet2_stack/src/pointnet2_api.cpp:23-24
+ * kernels              pointnet2_stack/src/interpolate_gpu.cu:107-126, :151-172
+ * features (M,C), idx/weight (N,3) -> out (N,C). */
+int mgar_three_interpolate_stack(int N, int C, const float *features, const int *idx, const float *weight,
+                                 float *out, void *stream);
+int mgar_three_interpolate_grad_stack(int N, int C, const float *grad_out, const int *idx, const float *weight,
+                                      float *grad_features, void *stream);
+
+/* ===================== third-party ops on the hot path ================================ */
+
+/* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).
+ * input (N,C,H,W), rois (K,5) [batch_index,x1,y1,x2,y2] -> out (K,C,ph,pw).
+ * sampling_ratio <= 0 = adaptive ceil(roi/pooled); aligned = 0 is the reference's mode.
+ * bwd accumulates into caller-zeroed grad_input (N,C,H,W). */
+int mgar_roi_align_fwd(const float *input, int N, int C, int H, int W, const float *rois, int K,
+                       int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
+                       float *out, void *stream);
+int mgar_roi_align_bwd(const float *grad_out, int N, int C, int H, int W, const float *rois, int K,
+                       int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
+                       float *grad_input, void *stream);
+
+/* DAFM distance-aware attention core (model/gat_model.py:487-491 and :503-505), batched
+ * over S scenes of n_s <= MGAR_DAFM_MAX_N actors each (scene_off: (S+1) row offsets).
+ *   E   = softmax(-De/sigma, dim=1)
+ *   Att = softmax((Q K^T * E) * scale, dim=1)
+ *   out = Att V
+ * q,k,v,out: (rows, D) row-major, D a multiple of 64; de: per scene a dense (n_s, n_s)
+ * block stored at de + de_off[s].  att (same layout as de) is saved for the backward.
+ * total_rows = scene_off[S] is passed by the host (it sizes the grid). */
+#define MGAR_DAFM_MAX_N 128
+int mgar_dafm_attn_fwd(int S, int total_rows, int D, const int *scene_off, const int *de_off, const float *q, const float *k,
+                       const float *v, const float *de, float sigma, float scale, float *att, float *out,
+                       void *stream);
+/* bwd: gmat is caller-allocated scratch with the layout of att (it receives
+ * dL/d(QK^T)); grad_q / grad_k / grad_v are fully written (no need to zero them). */
+int mgar_dafm_attn_bwd(int S, int total_rows, int D, const int *scene_off, const int *de_off, const float *q, const float *k,
+                       const float *v, const float *de, float sigma, float scale, const float *att,
+                       const float *grad_out, float *gmat, float *grad_q, float *grad_k, float *grad_v,
+                       void *stream);
+
+/* GATv2 edge-softmax + aggregate (torch_geometric.nn.GATv2Conv arithmetic; call site
+ * model/gat_model.py:1082-1094).  Edges are given in CSR form grouped by TARGET node:
+ * rowptr (n_nodes+1), col (E) = source node of each incoming edge (self loops included
+ * by the caller).  xl, xr: (n_nodes, H*C) = W_l x, W_r x;  att: (H, C).
+ *   e_ij   = att_h . leaky_relu(xl_j + xr_i, slope)
+ *   alpha  = softmax_j(e_ij)          (saved, (E,H))
+ *   out_i  = sum_j alpha_ij * xl_j    (n_nodes, H*C)
+ * bwd: grad_xl and grad_att are ACCUMULATED into (caller zero-fills them); grad_xr is
+ * fully written.
+ */
+/* C must be a multiple of 64 (lanes run along the channel axis). */
+int mgar_gatv2_fwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
+                   const float *xr, const float *att, float slope, float *alpha, float *out, void *stream);
+int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
+                   const float *xr, const float *att, float slope, const float *alpha, const float *grad_out,
+                   float *grad_xl, float *grad_xr, float *grad_att, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGAR_OPS_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libmgar_hip.so -- the ONLY way the Python host code reaches the kernels.
+
+The product path has no CPU fallback: if the HIP library is missing this module raises at
+import time, and every op refuses non-device tensors.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "multimodal_gar_amd: %s is missing -- build it with `python -m multimodal_gar_amd.build` "
+        "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+
+_cdll = ctypes.CDLL(LIB_PATH)
+
+_I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+
+# name -> argument ctypes, in the order of include/mgar_ops.h
+_PROTOS = {
+    "mgar_ball_query_batch": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "mgar_group_points_batch": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_group_points_grad_batch": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_gather_points_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_gather_points_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_fps_batch": [_I, _I, _I, _P, _P, _P, _P],
+    "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_three_interpolate_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_three_interpolate_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_ball_query_stack": [_I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_voxel_query_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_fps_stack": [_I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_group_points_stack": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_group_points_grad_stack": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_three_nn_stack": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_three_interpolate_stack": [_I, _I, _P, _P, _P, _P, _P],
+    "mgar_three_interpolate_grad_stack": [_I, _I, _P, _P, _P, _P, _P],
+    "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
+    "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
+    "mgar_dafm_attn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
+    "mgar_dafm_attn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
+    "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P],
+}
+
+_fns = {}
+for _name, _args in _PROTOS.items():
+    _fn = getattr(_cdll, _name)  # AttributeError here = the library is stale: rebuild it
+    _fn.argtypes = _args
+    _fn.restype = ctypes.c_int
+    _fns[_name] = _fn
+
+_cdll.mgar_abi_version.restype = ctypes.c_int
+_cdll.mgar_last_error.restype = ctypes.c_char_p
+if _cdll.mgar_abi_version() != ABI_VERSION:
+    raise ImportError("libmgar_hip.so ABI %d != expected %d: rebuild" % (_cdll.mgar_abi_version(), ABI_VERSION))
+
+
+class MgarError(RuntimeError):
+    pass
+
+
+def dev_ptr(t, dtype=None):
+    """Raw device pointer of a contiguous device tensor (the C ABI takes nothing else)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise MgarError("expected a device (HIP) tensor, got %s -- there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise MgarError("tensor must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise MgarError("expected dtype %s, got %s" % (dtype, t.dtype))
+    return t.data_ptr()
+
+
+def fptr(t):
+    return dev_ptr(t, torch.float32)
+
+
+def iptr(t):
+    return dev_ptr(t, torch.int32)
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def call(name, *args):
+    rc = _fns[name](*args)
+    if rc != 0:
+        raise MgarError("%s failed with code %d: %s" % (name, rc, _cdll.mgar_last_error().decode()))
+    return rc
+
+
+def exported_symbols():
+    return sorted(_PROTOS) + ["mgar_abi_version", "mgar_last_error"]

@@ -1,0 +1,95 @@
+// common.hpp -- shared helpers for the gfx950 kernels of libmgar_hip.so.
+// Written for CDNA4 only: 64-wide wavefronts, 160 KB LDS / CU, no dual-backend macros.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mgar_ops.h"
+
+namespace mgar {
+
+constexpr int kWave = 64;
+
+// Squared distance with the contraction pinned (see oracle/mgar_oracle.c header and
+// DESIGN.md "floating-point convention"): fma(dz,dz, fma(dx,dx, dy*dy)).
+// The library is compiled with -ffp-contract=off so nothing else is fused.
+__device__ __forceinline__ float d2_of(float dx, float dy, float dz) {
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dx, dx, dy * dy));
+}
+__device__ __forceinline__ float dot3_of(float w0, float p0, float w1, float p1, float w2, float p2) {
+    return __builtin_fmaf(w2, p2, __builtin_fmaf(w0, p0, w1 * p1));
+}
+
+// ---- wave-wide float reductions on the DPP crossbar (no LDS, no ds_bpermute) -----------
+// row_shr 1,2,4,8 leave each 16-lane row's total in its lane 15; row_bcast15/31 chain the
+// rows; the wave total sits in lane 63 and is returned wave-uniform through v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity),
+                                                                 __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_get<0x111, 0xF>(0.f, v);
+    v += dpp_get<0x112, 0xF>(0.f, v);
+    v += dpp_get<0x114, 0xF>(0.f, v);
+    v += dpp_get<0x118, 0xF>(0.f, v);
+    v += dpp_get<0x142, 0xA>(0.f, v);
+    v += dpp_get<0x143, 0xC>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    const float ninf = -__builtin_inff();
+    v = fmaxf(v, dpp_get<0x111, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_get<0x112, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_get<0x114, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_get<0x118, 0xF>(ninf, v));
+    v = fmaxf(v, dpp_get<0x142, 0xA>(ninf, v));
+    v = fmaxf(v, dpp_get<0x143, 0xC>(ninf, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+void set_error(const char *msg);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error(what);
+        return MGAR_ELAUNCH;
+    }
+    return MGAR_OK;
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#define MGAR_REQUIRE(cond, msg)        \
+    do {                               \
+        if (!(cond)) {                 \
+            ::mgar::set_error(msg);    \
+            return MGAR_EINVAL;        \
+        }                              \
+    } while (0)
+
+// Find the segment of a stacked layout that `pt` falls in and the prefix sums before it.
+// cnt_a: counts that define the segments of pt's own array; cnt_b: counts of the companion
+// array whose start offset is wanted.  Mirrors the per-thread search of
+// pointnet2_stack/src/ball_query_gpu.cu:27-35 but is only ever run wave-uniformly.
+struct Segment {
+    int bs;       // segment index
+    int a_start;  // start row of the segment in array a
+    int b_start;  // start row of the segment in array b
+};
+
+__device__ __forceinline__ Segment find_segment(int pt, int B, const int *__restrict__ cnt_a,
+                                                const int *__restrict__ cnt_b) {
+    Segment s{0, 0, 0};
+    int acc = cnt_a[0];
+    for (int k = 1; k < B; ++k) {
+        if (pt < acc) break;
+        s.a_start = acc;
+        s.b_start += cnt_b[k - 1];
+        acc += cnt_a[k];
+        s.bs = k;
+    }
+    return s;
+}
+
+}  // namespace mgar

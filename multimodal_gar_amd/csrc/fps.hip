@@ -1,0 +1,358 @@
+// fps.hip -- farthest point sampling (batch + stack layouts) for gfx950.
+//
+// Replaces  pcdet/ops/pointnet2/pointnet2_batch/src/sampling_gpu.cu:101-259
+//           pcdet/ops/pointnet2/pointnet2_stack/src/sampling_gpu.cu:188-348
+//
+// The reference keeps the cloud and the running min-distance array `temp` in global
+// memory and re-reads both (20 B/point) in every one of the m-1 serial rounds, then
+// reduces through a 10-step shared-memory tree with a __syncthreads per step.
+//
+// MI355X design: one workgroup per cloud (the rounds are a serial dependency chain), and
+//   * the whole cloud AND temp live in VGPRs for the entire kernel: up to 16 points per
+//     lane x 1024 lanes (4 VGPRs per point); HBM is touched once on the way in and once
+//     on the way out (12N + 4N + 4N + 4M bytes per cloud);
+//   * the per-round arg-max is a DPP (row_shr / row_bcast) reduction inside each wave, one
+//     32-byte LDS slot per wave, ONE barrier per round (slots are double-buffered), then a
+//     16-lane DPP reduction of the slots; the winner's coordinates travel with its key so
+//     no lane ever goes back to memory for the next round's reference point.
+//
+// Tie rule (bit-exact index parity).  The reference's result depends on its launch
+// geometry: thread tid scans k = tid, tid+bs, ... keeping the FIRST maximum (strict >),
+// and the tree "__update" keeps the lower slot unless the upper is strictly greater
+// (sampling_gpu.cu:93-98).  Unrolling the tree shows the survivor among equal maxima is
+// the candidate with the smallest  bitreverse_{log2 bs}(k mod bs), then the smallest k.
+// So every point gets the priority  p(k) = bitrev(k mod bs) * ceil(n/bs) + k / bs, lanes
+// visit their points in ascending p, and all reductions take max over (value, -p): any
+// reduction order then gives the reference's answer.  bs = min(2^floor(log2 n), 1024)
+// for the batch op (computed on the host with the reference's own double-precision
+// expression, cuda_utils.h:10-14) and 1024 for the stack op.
+#include <cmath>
+#include "common.hpp"
+
+namespace mgar {
+
+template <int N> struct VecOf {
+    typedef float __attribute__((ext_vector_type(N))) f;
+    typedef int __attribute__((ext_vector_type(N))) i;
+};
+
+// ---- DPP helpers (gfx9 encodings) -------------------------------------------------
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_umax64(unsigned long long key) {
+    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+    // lanes without a valid source (or outside ROW_MASK) receive 0 = the identity of umax
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, ROW_MASK, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, ROW_MASK, 0xF, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > key ? o : key;
+}
+
+// max over each 16-lane row, result in lane 15 of the row
+__device__ __forceinline__ unsigned long long row_umax64(unsigned long long key) {
+    key = dpp_umax64<DPP_ROW_SHR1, 0xF>(key);
+    key = dpp_umax64<DPP_ROW_SHR2, 0xF>(key);
+    key = dpp_umax64<DPP_ROW_SHR4, 0xF>(key);
+    key = dpp_umax64<DPP_ROW_SHR8, 0xF>(key);
+    return key;
+}
+
+// max over the wave, returned wave-uniform
+__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long key) {
+    key = row_umax64(key);
+    key = dpp_umax64<DPP_ROW_BCAST15, 0xA>(key);
+    key = dpp_umax64<DPP_ROW_BCAST31, 0xC>(key);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Single-instruction min / max.  fminf()/fmaxf() make hipcc emit a canonicalising
+// v_max_f32 x,x in front of every v_min/v_max (IEEE mode sNaN quieting): +1 VALU per
+// point per round in a loop that is VALU-bound.  Inputs here are never NaN.
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// order-preserving float -> uint
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+    const unsigned b = __float_as_uint(v);
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+
+struct FpsArgs {
+    int stack;           // 0 = batch layout, 1 = stacked layout
+    int n_batch, m_batch, bs_log2_batch;
+    const float *points;
+    float *temp;
+    const int *xyz_batch_cnt;
+    int *idx;
+    const int *num_sampled;
+};
+
+struct alignas(32) FpsSlot {
+    unsigned key_lo, key_hi;
+    float x, y, z;
+    int k;
+    int pad0, pad1;
+};
+
+// slot s of thread t  ->  point index (ascending priority inside a thread); see header.
+//   R = max(bs/T, 1) residues per thread, L = ceil(n/bs) points per residue
+__device__ __forceinline__ int slot_to_k(int t, int s, int T, int bs_log2, int R_log2, int L) {
+    const int ap = s / L, j = s - ap * L;
+    const int a = R_log2 ? (int)(__brev((unsigned)ap) >> (32 - R_log2)) : 0;
+    return t + a * T + (j << bs_log2);
+}
+
+template <int T, int PPT>
+__global__ __launch_bounds__(T) void fps_kernel(FpsArgs A) {
+    constexpr int NW = T / kWave;
+    __shared__ FpsSlot slots[2][16];
+
+    const int cloud = blockIdx.x;
+    int start, ostart, n, m, bs_log2, idx_off;
+    if (A.stack) {
+        start = 0; ostart = 0;
+        for (int i = 0; i < cloud; ++i) { start += A.xyz_batch_cnt[i]; ostart += A.num_sampled[i]; }
+        n = A.xyz_batch_cnt[cloud];
+        m = A.num_sampled[cloud];
+        bs_log2 = 10;
+        idx_off = start;  // stack op writes global row ids (sampling_gpu.cu:313-315)
+    } else {
+        start = cloud * A.n_batch; ostart = cloud * A.m_batch;
+        n = A.n_batch; m = A.m_batch; bs_log2 = A.bs_log2_batch;
+        idx_off = 0;
+    }
+    if (m <= 0 || n <= 0) return;
+
+    const float *__restrict__ P = A.points + (size_t)start * 3;
+    float *__restrict__ temp = A.temp + start;
+    int *__restrict__ out = A.idx + ostart;
+
+    const int tid = threadIdx.x;
+    const int bs = 1 << bs_log2;
+    const int L = (n + bs - 1) >> bs_log2;
+    int R_log2 = 0;
+    while ((T << R_log2) < bs) ++R_log2;
+    const int used = L << R_log2;       // slots that can hold a real point (<= PPT by dispatch)
+    const bool lane_active = tid < bs;  // T > bs only for tiny clouds
+    // Priority of slot s of this lane is  prio_base + s  (see header: the bit-reversed
+    // residue of k = tid + a*T splits into bitrev(tid) and the slot's residue rank).
+    const int t_log2 = (T < bs ? __builtin_ctz((unsigned)T) : bs_log2);
+    const unsigned rev_t = t_log2 ? (__brev((unsigned)tid) >> (32 - t_log2)) : 0u;
+    const unsigned prio_base = (rev_t << R_log2) * (unsigned)L;
+
+    typename VecOf<PPT>::f X, Y, Z, D;
+    typename VecOf<PPT>::i K;
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int k = slot_to_k(tid, s, T, bs_log2, R_log2, L);
+        const bool ok = lane_active && s < used && k < n;
+        K[s] = ok ? k : -1;
+        X[s] = ok ? P[k * 3 + 0] : 0.f;
+        Y[s] = ok ? P[k * 3 + 1] : 0.f;
+        Z[s] = ok ? P[k * 3 + 2] : 0.f;
+        D[s] = ok ? temp[k] : -1.f;  // padding can never beat a real candidate (d2 >= 0)
+    }
+
+    float x1 = P[0], y1 = P[1], z1 = P[2];
+    if (tid == 0) out[0] = idx_off;
+
+    const int lane = tid & 63, wave = tid >> 6;
+
+    for (int j = 1; j < m; ++j) {
+        // ---- per-lane scan in ascending priority, strict '>' keeps the first maximum ----
+        float best = -1.f;
+        int bslot = 0;
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const float d = d2_of(X[s] - x1, Y[s] - y1, Z[s] - z1);
+            const float d2 = vmin(d, D[s]);
+            D[s] = d2;
+            bslot = d2 > best ? s : bslot;
+            best = vmax(best, d2);
+        }
+        const unsigned long long mykey = ((unsigned long long)ordered_bits(best) << 32) |
+                                         (unsigned long long)(0xFFFFFFFFu - (prio_base + (unsigned)bslot));
+
+        // ---- wave arg-max; the unique winning lane publishes key + coordinates ----
+        const unsigned long long wkey = wave_umax64(mykey);
+        FpsSlot *buf = slots[j & 1];
+        if (mykey == wkey) {  // exactly one lane: priorities are unique
+            FpsSlot sl;
+            sl.key_lo = (unsigned)wkey; sl.key_hi = (unsigned)(wkey >> 32);
+            // one active lane => its slot number is wave-uniform: index the register
+            // arrays through an SGPR instead of a 15-deep select chain per array
+            const int us = __builtin_amdgcn_readfirstlane(bslot);
+            sl.x = X[us]; sl.y = Y[us]; sl.z = Z[us];
+            sl.k = K[us]; sl.pad0 = 0; sl.pad1 = 0;
+            buf[wave] = sl;
+        }
+        int win_k;
+        if (NW > 1) {
+            __syncthreads();
+            // ---- 16-lane reduction over the per-wave slots (every row does the same) ----
+            const int w = lane & 15;
+            const FpsSlot sl = buf[w < NW ? w : 0];
+            const unsigned long long skey = w < NW ? (((unsigned long long)sl.key_hi << 32) | sl.key_lo) : 0ull;
+            const unsigned long long rkey = row_umax64(skey);
+            const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rkey, 15);
+            const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rkey >> 32), 15);
+            const unsigned long long gkey = ((unsigned long long)rhi << 32) | rlo;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(skey == gkey && w < NW);
+            const int src = __builtin_ctzll(hit);  // first lane holding the winning slot
+            x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.x), src));
+            y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.y), src));
+            z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.z), src));
+            win_k = __builtin_amdgcn_readlane(sl.k, src);
+        } else {
+            // single wave: the slot written above is already the global winner; LDS ops of
+            // one wave execute in order, so the read below sees the write
+            __builtin_amdgcn_wave_barrier();
+            const FpsSlot sl = buf[0];
+            x1 = sl.x; y1 = sl.y; z1 = sl.z; win_k = sl.k;
+        }
+        if (tid == 0) out[j] = win_k + idx_off;
+    }
+
+    // ---- temp is an in/out argument of the reference op: hand the final values back ----
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        if (K[s] >= 0) temp[K[s]] = D[s];
+    }
+}
+
+// Fallback for clouds that do not fit the register file (n > 16384): same reduction
+// machinery, but coordinates and temp are streamed from memory every round like the
+// reference does.  Correctness path only.
+__global__ __launch_bounds__(1024) void fps_stream_kernel(FpsArgs A) {
+    constexpr int NW = 16;
+    __shared__ FpsSlot slots[2][16];
+    const int cloud = blockIdx.x;
+    int start, ostart, n, m, bs_log2, idx_off;
+    if (A.stack) {
+        start = 0; ostart = 0;
+        for (int i = 0; i < cloud; ++i) { start += A.xyz_batch_cnt[i]; ostart += A.num_sampled[i]; }
+        n = A.xyz_batch_cnt[cloud]; m = A.num_sampled[cloud]; bs_log2 = 10; idx_off = start;
+    } else {
+        start = cloud * A.n_batch; ostart = cloud * A.m_batch;
+        n = A.n_batch; m = A.m_batch; bs_log2 = A.bs_log2_batch; idx_off = 0;
+    }
+    if (m <= 0 || n <= 0) return;
+    const float *__restrict__ P = A.points + (size_t)start * 3;
+    float *__restrict__ temp = A.temp + start;
+    int *__restrict__ out = A.idx + ostart;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bs = 1 << bs_log2;
+    const int L = (n + bs - 1) >> bs_log2;
+    float x1 = P[0], y1 = P[1], z1 = P[2];
+    if (tid == 0) out[0] = idx_off;
+    for (int j = 1; j < m; ++j) {
+        float best = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+        int bk = 0;
+        if (tid < bs) {
+            for (int k = tid; k < n; k += bs) {  // bs == T here (n > 16384 => bs = 1024)
+                const float x2 = P[k * 3 + 0], y2 = P[k * 3 + 1], z2 = P[k * 3 + 2];
+                const float d = d2_of(x2 - x1, y2 - y1, z2 - z1);
+                const float d2 = vmin(d, temp[k]);
+                temp[k] = d2;
+                if (d2 > best) { best = d2; bk = k; bx = x2; by = y2; bz = z2; }
+            }
+        }
+        const unsigned prio = (__brev((unsigned)(bk & (bs - 1))) >> (32 - bs_log2)) * (unsigned)L + (unsigned)(bk >> bs_log2);
+        const unsigned long long mykey = ((unsigned long long)ordered_bits(best) << 32) | (unsigned long long)(0xFFFFFFFFu - prio);
+        const unsigned long long wkey = wave_umax64(mykey);
+        FpsSlot *buf = slots[j & 1];
+        if (mykey == wkey) {
+            FpsSlot sl;
+            sl.key_lo = (unsigned)wkey; sl.key_hi = (unsigned)(wkey >> 32);
+            sl.x = bx; sl.y = by; sl.z = bz; sl.k = bk; sl.pad0 = 0; sl.pad1 = 0;
+            buf[wave] = sl;
+        }
+        __syncthreads();
+        const int w = lane & 15;
+        FpsSlot sl = buf[w < NW ? w : 0];
+        unsigned long long skey = ((unsigned long long)sl.key_hi << 32) | sl.key_lo;
+        unsigned long long rkey = row_umax64(skey);
+        const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rkey, 15);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rkey >> 32), 15);
+        const unsigned long long gkey = ((unsigned long long)rhi << 32) | rlo;
+        const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(skey == gkey));
+        x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.x), src));
+        y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.y), src));
+        z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.z), src));
+        const int win_k = __builtin_amdgcn_readlane(sl.k, src);
+        if (tid == 0) out[j] = win_k + idx_off;
+    }
+}
+
+template <int T>
+static bool launch_fps_t(int ppt_needed, int nclouds, const FpsArgs &A, hipStream_t st) {
+    if (ppt_needed <= 1) hipLaunchKernelGGL((fps_kernel<T, 1>), dim3(nclouds), dim3(T), 0, st, A);
+    else if (ppt_needed <= 2) hipLaunchKernelGGL((fps_kernel<T, 2>), dim3(nclouds), dim3(T), 0, st, A);
+    else if (ppt_needed <= 4) hipLaunchKernelGGL((fps_kernel<T, 4>), dim3(nclouds), dim3(T), 0, st, A);
+    else if (ppt_needed <= 8) hipLaunchKernelGGL((fps_kernel<T, 8>), dim3(nclouds), dim3(T), 0, st, A);
+    else if (ppt_needed <= 16) hipLaunchKernelGGL((fps_kernel<T, 16>), dim3(nclouds), dim3(T), 0, st, A);
+    else return false;
+    return true;
+}
+
+// n_max: an upper bound of the points in any one cloud; bs_log2: log2 of the reference's
+// block size (it fixes the tie rule, not our launch geometry).
+static int fps_dispatch(int nclouds, int n_max, int bs_log2, const FpsArgs &A, hipStream_t st) {
+    const int bs = 1 << bs_log2;
+    const int L = (n_max + bs - 1) / bs;
+    // our workgroup: the largest of {1024, 256, 64} lanes that does not exceed bs (so every
+    // lane owns whole residues), but never fewer than 64
+    const int T = bs >= 1024 ? 1024 : (bs >= 256 ? 256 : 64);
+    const int R = bs > T ? bs / T : 1;
+    const int need = L * R;  // register slots per lane
+    bool ok;
+    if (T == 1024) ok = launch_fps_t<1024>(need, nclouds, A, st);
+    else if (T == 256) ok = launch_fps_t<256>(need, nclouds, A, st);
+    else ok = launch_fps_t<64>(need, nclouds, A, st);
+    if (!ok) {
+        // does not fit the register file: only possible with bs == 1024 and n_max > 16384
+        hipLaunchKernelGGL(fps_stream_kernel, dim3(nclouds), dim3(1024), 0, st, A);
+    }
+    return check_launch("fps: launch failed");
+}
+
+}  // namespace mgar
+
+using namespace mgar;
+
+extern "C" __attribute__((visibility("default"))) int mgar_fps_batch(int b, int n, int m, const float *points, float *temp, int *idx, void *stream) {
+    MGAR_REQUIRE(b >= 0 && n >= 0 && m >= 0, "fps_batch: negative size");
+    if (b == 0 || m == 0) return MGAR_OK;
+    MGAR_REQUIRE(n > 0, "fps_batch: m > 0 samples requested from an empty cloud");
+    MGAR_REQUIRE(points && temp && idx, "fps_batch: null pointer");
+    // the reference's block size: pointnet2_batch/src/cuda_utils.h:10-14, same expression
+    const int pow_2 = (int)(std::log(static_cast<double>(n)) / std::log(2.0));
+    int bs = 1 << pow_2;
+    bs = bs > 1024 ? 1024 : (bs < 1 ? 1 : bs);
+    int bs_log2 = 0;
+    while ((1 << bs_log2) < bs) ++bs_log2;
+    FpsArgs A{0, n, m, bs_log2, points, temp, nullptr, idx, nullptr};
+    return fps_dispatch(b, n, bs_log2, A, (hipStream_t)stream);
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_fps_stack(int batch_size, int N, const float *points, float *temp, const int *xyz_batch_cnt,
+                              int *idx, const int *num_sampled_points, void *stream) {
+    MGAR_REQUIRE(batch_size >= 0 && N >= 0, "fps_stack: negative size");
+    if (batch_size == 0 || N == 0) return MGAR_OK;
+    MGAR_REQUIRE(points && temp && idx && xyz_batch_cnt && num_sampled_points, "fps_stack: null pointer");
+    FpsArgs A{1, 0, 0, 10, points, temp, xyz_batch_cnt, idx, num_sampled_points};
+    // per-cloud sizes live on the device; N (their sum) bounds every one of them
+    return fps_dispatch(batch_size, N, 10, A, (hipStream_t)stream);
+}

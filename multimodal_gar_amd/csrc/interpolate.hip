@@ -1,0 +1,298 @@
+// interpolate.hip -- three nearest neighbours + inverse-distance interpolation
+// (fwd + bwd), batch and stack layouts, for gfx950.
+//
+// Replaces  pointnet2_batch/src/interpolate_gpu.cu:16-168
+//           pointnet2_stack/src/interpolate_gpu.cu:16-194
+//
+// three_nn: one lane per unknown point; the known cloud is a wave-uniform stream through
+// the scalar cache (same structure as ball_query.hip).  The reference's strict-'<' cascade
+// is kept verbatim so equal distances resolve to the earlier index; it sits behind a
+// wave-uniform branch ("does any lane improve its 3rd best?"), so the steady state is the
+// 7-VALU distance evaluation + 1 compare per pair.
+//
+// three_interpolate: bandwidth-bound gathers.  Batch layout (B,C,M): a thread owns one
+// output point and walks the channels (idx/weight read once, not once per channel).
+// Stack layout (M,C): lanes run along c so every access is a contiguous feature row;
+// the backward's float atomics therefore cover whole row segments.
+#include "common.hpp"
+
+namespace mgar {
+
+constexpr int TN_THREADS = 256;
+constexpr int TN_CHUNK = 16;
+typedef const float __attribute__((address_space(4))) *cfloat_p;
+
+template <bool STACK>
+__global__ __launch_bounds__(TN_THREADS) void three_nn_kernel(int B, int n_batch, int m_batch,
+                                                              const float *__restrict__ unknown,
+                                                              const int *__restrict__ unknown_batch_cnt,
+                                                              const float *__restrict__ known,
+                                                              const int *__restrict__ known_batch_cnt,
+                                                              float *__restrict__ dist2, int *__restrict__ idx) {
+    int u0, u_end, k_start, m;
+    if (STACK) {
+        int g = blockIdx.x, us = 0, ks = 0, bs = 0;
+        bool found = false;
+        for (; bs < B; ++bs) {
+            const int ni = unknown_batch_cnt[bs];
+            const int nb = (ni + TN_THREADS - 1) / TN_THREADS;
+            if (g < nb) { found = true; break; }
+            g -= nb;
+            us += ni;
+            ks += known_batch_cnt[bs];
+        }
+        if (!found) return;
+        u0 = us + g * TN_THREADS;
+        u_end = us + unknown_batch_cnt[bs];
+        k_start = ks;
+        m = known_batch_cnt[bs];
+    } else {
+        const int bs = blockIdx.y;
+        u0 = bs * n_batch + blockIdx.x * TN_THREADS;
+        u_end = (bs + 1) * n_batch;
+        k_start = bs * m_batch;
+        m = m_batch;
+    }
+    const int u = u0 + threadIdx.x;
+    const bool valid = u < u_end;
+    // lanes without a point carry NaN: every "d < best" is false, so they never trigger
+    // the wave-uniform update branch
+    float ux = __builtin_nanf(""), uy = 0.f, uz = 0.f;
+    if (valid) {
+        ux = unknown[(size_t)u * 3 + 0];
+        uy = unknown[(size_t)u * 3 + 1];
+        uz = unknown[(size_t)u * 3 + 2];
+    }
+    // reference: double best = 1e40 stored to float -> +inf for unfilled slots
+    float best1 = __builtin_inff(), best2 = __builtin_inff(), best3 = __builtin_inff();
+    int besti1 = 0, besti2 = 0, besti3 = 0;
+    cfloat_p K = (cfloat_p)(known + (size_t)k_start * 3);
+
+    auto consider = [&](float d, int k) {
+        if (d < best1) {
+            best3 = best2; besti3 = besti2;
+            best2 = best1; besti2 = besti1;
+            best1 = d; besti1 = k;
+        } else if (d < best2) {
+            best3 = best2; besti3 = besti2;
+            best2 = d; besti2 = k;
+        } else if (d < best3) {
+            best3 = d; besti3 = k;
+        }
+    };
+
+    int k0 = 0;
+    for (; k0 + TN_CHUNK <= m; k0 += TN_CHUNK) {
+        float c[TN_CHUNK * 3];
+#pragma unroll
+        for (int i = 0; i < TN_CHUNK * 3; ++i) c[i] = K[k0 * 3 + i];
+#pragma unroll
+        for (int j = 0; j < TN_CHUNK; ++j) {
+            const float d = d2_of(ux - c[j * 3 + 0], uy - c[j * 3 + 1], uz - c[j * 3 + 2]);
+            if (d < best3) {  // d < best1 or d < best2 imply d < best3 (best1 <= best2 <= best3)
+                asm volatile("; top-3 update" ::: "memory");  // keep the execz skip branch
+                consider(d, k0 + j);
+            }
+        }
+    }
+    for (int k = k0; k < m; ++k) {
+        const float d = d2_of(ux - K[k * 3 + 0], uy - K[k * 3 + 1], uz - K[k * 3 + 2]);
+        consider(d, k);
+    }
+    if (valid) {
+        const int off = STACK ? k_start : 0;  // stack op returns global rows (interpolate_gpu.cu:72-74)
+        dist2[(size_t)u * 3 + 0] = best1; dist2[(size_t)u * 3 + 1] = best2; dist2[(size_t)u * 3 + 2] = best3;
+        idx[(size_t)u * 3 + 0] = besti1 + off; idx[(size_t)u * 3 + 1] = besti2 + off; idx[(size_t)u * 3 + 2] = besti3 + off;
+    }
+}
+
+// ------------------------- three_interpolate, batch layout -------------------------
+constexpr int TI_CCHUNK = 8;
+
+// grid (ceil(n/256), ceil(c/TI_CCHUNK), b)
+__global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int m, int n,
+                                                                     const float *__restrict__ points,
+                                                                     const int *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     float *__restrict__ out) {
+    const int pt = blockIdx.x * 256 + threadIdx.x;
+    if (pt >= n) return;
+    const int bs = blockIdx.z;
+    const int c0 = blockIdx.y * TI_CCHUNK, c1 = min(c0 + TI_CCHUNK, c);
+    const size_t o = ((size_t)bs * n + pt) * 3;
+    const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
+    const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
+    const float *src = points + ((size_t)bs * c + c0) * m;
+    float *dst = out + ((size_t)bs * c + c0) * n + pt;
+    for (int ci = c0; ci < c1; ++ci) {
+        *dst = dot3_of(w0, src[i0], w1, src[i1], w2, src[i2]);
+        src += m;
+        dst += n;
+    }
+}
+
+// one workgroup per (b, c) row of grad_points (m floats in LDS), like the grouping backward
+__global__ __launch_bounds__(1024) void three_interp_batch_bwd_lds_kernel(int c, int n, int m,
+                                                                          const float *__restrict__ grad_out,
+                                                                          const int *__restrict__ idx,
+                                                                          const float *__restrict__ weight,
+                                                                          float *__restrict__ grad_points) {
+    extern __shared__ float row[];
+    const int ci = blockIdx.x, bs = blockIdx.y;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) row[i] = 0.f;
+    __syncthreads();
+    const float *g = grad_out + ((size_t)bs * c + ci) * n;
+    for (int pt = threadIdx.x; pt < n; pt += blockDim.x) {
+        const size_t o = ((size_t)bs * n + pt) * 3;
+        const float gv = g[pt];
+        atomicAdd(&row[idx[o + 0]], gv * weight[o + 0]);
+        atomicAdd(&row[idx[o + 1]], gv * weight[o + 1]);
+        atomicAdd(&row[idx[o + 2]], gv * weight[o + 2]);
+    }
+    __syncthreads();
+    float *dst = grad_points + ((size_t)bs * c + ci) * m;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const float v = row[i];
+        if (v != 0.f) dst[i] += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void three_interp_batch_bwd_atomic_kernel(int c, int n, int m,
+                                                                            const float *__restrict__ grad_out,
+                                                                            const int *__restrict__ idx,
+                                                                            const float *__restrict__ weight,
+                                                                            float *__restrict__ grad_points) {
+    const int pt = blockIdx.x * 256 + threadIdx.x;
+    if (pt >= n) return;
+    const int ci = blockIdx.y, bs = blockIdx.z;
+    const size_t o = ((size_t)bs * n + pt) * 3;
+    const float gv = grad_out[((size_t)bs * c + ci) * n + pt];
+    float *G = grad_points + ((size_t)bs * c + ci) * m;
+    atomicAdd(G + idx[o + 0], gv * weight[o + 0]);
+    atomicAdd(G + idx[o + 1], gv * weight[o + 1]);
+    atomicAdd(G + idx[o + 2], gv * weight[o + 2]);
+}
+
+// ------------------------- three_interpolate, stack layout -------------------------
+// flat index e = pt*C + ci, lanes along c
+__global__ __launch_bounds__(256) void three_interp_stack_fwd_kernel(long long total, int C,
+                                                                     const float *__restrict__ features,
+                                                                     const int *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     float *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long pt = e / C;
+        const int ci = (int)(e - pt * C);
+        const int i0 = idx[pt * 3], i1 = idx[pt * 3 + 1], i2 = idx[pt * 3 + 2];
+        const float w0 = weight[pt * 3], w1 = weight[pt * 3 + 1], w2 = weight[pt * 3 + 2];
+        out[e] = dot3_of(w0, features[(size_t)i0 * C + ci], w1, features[(size_t)i1 * C + ci], w2,
+                         features[(size_t)i2 * C + ci]);
+    }
+}
+
+__global__ __launch_bounds__(256) void three_interp_stack_bwd_kernel(long long total, int C,
+                                                                     const float *__restrict__ grad_out,
+                                                                     const int *__restrict__ idx,
+                                                                     const float *__restrict__ weight,
+                                                                     float *__restrict__ grad_features) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long pt = e / C;
+        const int ci = (int)(e - pt * C);
+        const float gv = grad_out[e];
+        atomicAdd(grad_features + (size_t)idx[pt * 3 + 0] * C + ci, gv * weight[pt * 3 + 0]);
+        atomicAdd(grad_features + (size_t)idx[pt * 3 + 1] * C + ci, gv * weight[pt * 3 + 1]);
+        atomicAdd(grad_features + (size_t)idx[pt * 3 + 2] * C + ci, gv * weight[pt * 3 + 2]);
+    }
+}
+
+constexpr int TI_LDS_MAX_FLOATS = 36864;
+
+}  // namespace mgar
+
+using namespace mgar;
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_nn_batch(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                                   int *idx, void *stream) {
+    MGAR_REQUIRE(b >= 0 && n >= 0 && m >= 0, "three_nn_batch: negative size");
+    MGAR_REQUIRE(b <= 65535, "three_nn_batch: b > 65535");
+    if (b == 0 || n == 0) return MGAR_OK;
+    MGAR_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn_batch: null pointer");
+    dim3 grid(ceil_div(n, TN_THREADS), b);
+    hipLaunchKernelGGL(three_nn_kernel<false>, grid, dim3(TN_THREADS), 0, (hipStream_t)stream, b, n, m, unknown,
+                       (const int *)nullptr, known, (const int *)nullptr, dist2, idx);
+    return check_launch("three_nn_batch: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_nn_stack(int batch_size, int N, int M, const float *unknown, const int *unknown_batch_cnt,
+                                   const float *known, const int *known_batch_cnt, float *dist2, int *idx,
+                                   void *stream) {
+    MGAR_REQUIRE(batch_size >= 0 && N >= 0 && M >= 0, "three_nn_stack: negative size");
+    if (batch_size == 0 || N == 0) return MGAR_OK;
+    MGAR_REQUIRE(unknown && dist2 && idx && unknown_batch_cnt && known_batch_cnt && (known || M == 0),
+                 "three_nn_stack: null pointer");
+    dim3 grid(ceil_div(N, TN_THREADS) + batch_size);
+    hipLaunchKernelGGL(three_nn_kernel<true>, grid, dim3(TN_THREADS), 0, (hipStream_t)stream, batch_size, 0, 0, unknown,
+                       unknown_batch_cnt, known, known_batch_cnt, dist2, idx);
+    return check_launch("three_nn_stack: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch(int b, int c, int m, int n, const float *points, const int *idx,
+                                            const float *weight, float *out, void *stream) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_batch: negative size");
+    MGAR_REQUIRE(b <= 65535, "three_interpolate_batch: b > 65535");
+    if ((long long)b * c * n == 0) return MGAR_OK;
+    MGAR_REQUIRE(points && idx && weight && out, "three_interpolate_batch: null pointer");
+    dim3 grid(ceil_div(n, 256), ceil_div(c, TI_CCHUNK), b);
+    hipLaunchKernelGGL(three_interp_batch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx,
+                       weight, out);
+    return check_launch("three_interpolate_batch: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                                 const float *weight, float *grad_points, void *stream) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad_batch: negative size");
+    MGAR_REQUIRE(b <= 65535 && c <= 65535, "three_interpolate_grad_batch: b or c > 65535");
+    if ((long long)b * c * n == 0) return MGAR_OK;
+    MGAR_REQUIRE(grad_out && idx && weight && grad_points, "three_interpolate_grad_batch: null pointer");
+    if (m <= TI_LDS_MAX_FLOATS) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)three_interp_batch_bwd_lds_kernel,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      TI_LDS_MAX_FLOATS * (int)sizeof(float));
+            attr_set = true;
+        }
+        const int threads = n >= 4096 ? 1024 : 256;
+        hipLaunchKernelGGL(three_interp_batch_bwd_lds_kernel, dim3(c, b), dim3(threads), (size_t)m * sizeof(float),
+                           (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    } else {
+        dim3 grid(ceil_div(n, 256), c, b);
+        hipLaunchKernelGGL(three_interp_batch_bwd_atomic_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, m,
+                           grad_out, idx, weight, grad_points);
+    }
+    return check_launch("three_interpolate_grad_batch: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_stack(int N, int C, const float *features, const int *idx, const float *weight,
+                                            float *out, void *stream) {
+    MGAR_REQUIRE(N >= 0 && C >= 0, "three_interpolate_stack: negative size");
+    const long long total = (long long)N * C;
+    if (total == 0) return MGAR_OK;
+    MGAR_REQUIRE(features && idx && weight && out, "three_interpolate_stack: null pointer");
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(three_interp_stack_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, C,
+                       features, idx, weight, out);
+    return check_launch("three_interpolate_stack: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_stack(int N, int C, const float *grad_out, const int *idx,
+                                                 const float *weight, float *grad_features, void *stream) {
+    MGAR_REQUIRE(N >= 0 && C >= 0, "three_interpolate_grad_stack: negative size");
+    const long long total = (long long)N * C;
+    if (total == 0) return MGAR_OK;
+    MGAR_REQUIRE(grad_out && idx && weight && grad_features, "three_interpolate_grad_stack: null pointer");
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(three_interp_stack_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, C,
+                       grad_out, idx, weight, grad_features);
+    return check_launch("three_interpolate_grad_stack: launch failed");
+}

@@ -1,0 +1,118 @@
+// voxel_query.hip -- neighbour-voxel query (stack layout) for gfx950.
+//
+// Replaces  pcdet/ops/pointnet2/pointnet2_stack/src/voxel_query_gpu.cu:10-113
+//
+// One lane per query.  Each query walks the (2z+1)(2y+1)(2x+1) cells around its voxel in
+// the reference's dz, dy, dx ascending order, looks the cell up in the dense
+// point_indices (B,Z,Y,X) table and tests the voxel centre with d2 <= r^2 (NON-strict,
+// voxel_query_gpu.cu:65).  This is latency-bound dependent gathers (4 B table lookup, then
+// 12 B xyz on occupied cells), so the kernel is organised to keep many loads in flight:
+// a whole x-row of the neighbourhood (2x+1 consecutive table entries) is fetched before any
+// of it is consumed, and occupancy is high (no LDS in the scan, < 48 VGPRs).
+// The hit rows are staged in LDS [slot][query] and written out coalesced with the
+// first-hit padding, exactly like ball_query.hip.  A lane stops appending at nsample hits
+// (the reference keeps scanning but can no longer change its row).
+#include "common.hpp"
+
+namespace mgar {
+
+constexpr int VQ_THREADS = 256;
+constexpr int VQ_ROW_STRIDE = VQ_THREADS + 1;
+constexpr int VQ_MAX_XROW = 17;  // x_range <= 8 handled with the row prefetch
+
+__global__ __launch_bounds__(VQ_THREADS) void voxel_query_kernel(int M, int R1, int R2, int R3, int nsample,
+                                                                 float radius2, int z_range, int y_range, int x_range,
+                                                                 const float *__restrict__ new_xyz,
+                                                                 const float *__restrict__ xyz,
+                                                                 const int *__restrict__ new_coords,
+                                                                 const int *__restrict__ point_indices,
+                                                                 int *__restrict__ idx) {
+    extern __shared__ int lds[];
+    int *rows = lds;
+    int *cnts = lds + nsample * VQ_ROW_STRIDE;
+    const int tid = threadIdx.x;
+    const int q0 = blockIdx.x * VQ_THREADS;
+    const int q = q0 + tid;
+    int cnt = 0;
+    if (q < M) {
+        const float nx = new_xyz[(size_t)q * 3 + 0], ny = new_xyz[(size_t)q * 3 + 1], nz = new_xyz[(size_t)q * 3 + 2];
+        const int b = new_coords[(size_t)q * 4 + 0], cz = new_coords[(size_t)q * 4 + 1];
+        const int cy = new_coords[(size_t)q * 4 + 2], cx = new_coords[(size_t)q * 4 + 3];
+        const int x_lo = max(cx - x_range, 0), x_hi = min(cx + x_range, R3 - 1);
+        const int z_lo = max(cz - z_range, 0), z_hi = min(cz + z_range, R1 - 1);
+        const int y_lo = max(cy - y_range, 0), y_hi = min(cy + y_range, R2 - 1);
+        const bool prefetch_rows = (2 * x_range + 1) <= VQ_MAX_XROW;
+        for (int z = z_lo; z <= z_hi && cnt < nsample; ++z) {
+            for (int y = y_lo; y <= y_hi && cnt < nsample; ++y) {
+                const int *cell = point_indices + (((size_t)b * R1 + z) * R2 + y) * R3;
+                if (prefetch_rows) {
+                    int nb[VQ_MAX_XROW];
+#pragma unroll
+                    for (int i = 0; i < VQ_MAX_XROW; ++i) {
+                        const int x = x_lo + i;
+                        nb[i] = x <= x_hi ? cell[x] : -1;
+                    }
+#pragma unroll
+                    for (int i = 0; i < VQ_MAX_XROW; ++i) {
+                        const int k = nb[i];
+                        if (k < 0 || cnt >= nsample) continue;
+                        const float d2 = d2_of(xyz[(size_t)k * 3 + 0] - nx, xyz[(size_t)k * 3 + 1] - ny,
+                                               xyz[(size_t)k * 3 + 2] - nz);
+                        if (d2 > radius2) continue;
+                        rows[cnt * VQ_ROW_STRIDE + tid] = k;
+                        ++cnt;
+                    }
+                } else {
+                    for (int x = x_lo; x <= x_hi && cnt < nsample; ++x) {
+                        const int k = cell[x];
+                        if (k < 0) continue;
+                        const float d2 = d2_of(xyz[(size_t)k * 3 + 0] - nx, xyz[(size_t)k * 3 + 1] - ny,
+                                               xyz[(size_t)k * 3 + 2] - nz);
+                        if (d2 > radius2) continue;
+                        rows[cnt * VQ_ROW_STRIDE + tid] = k;
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+    cnts[tid] = cnt;
+    __syncthreads();
+    const int nq = min(VQ_THREADS, M - q0);
+    const int total = nq * nsample;
+    int *out = idx + (size_t)q0 * nsample;
+    for (int e = tid; e < total; e += VQ_THREADS) {
+        const int ql = e / nsample, s = e - ql * nsample;
+        const int c = cnts[ql];
+        if (c > 0) out[e] = rows[(s < c ? s : 0) * VQ_ROW_STRIDE + ql];
+        else if (s == 0) out[e] = -1;  // voxel_query_gpu.cu:88
+    }
+}
+
+}  // namespace mgar
+
+using namespace mgar;
+
+extern "C" __attribute__((visibility("default"))) int mgar_voxel_query_stack(int M, int R1, int R2, int R3, int nsample, float radius, int z_range,
+                                      int y_range, int x_range, const float *new_xyz, const float *xyz,
+                                      const int *new_coords, const int *point_indices, int *idx, void *stream) {
+    MGAR_REQUIRE(M >= 0 && R1 > 0 && R2 > 0 && R3 > 0, "voxel_query: bad grid size");
+    MGAR_REQUIRE(z_range >= 0 && y_range >= 0 && x_range >= 0, "voxel_query: negative range");
+    if (nsample < 1 || nsample > MGAR_MAX_NSAMPLE) {
+        set_error("voxel_query: nsample outside [1, MGAR_MAX_NSAMPLE]");
+        return MGAR_EUNSUPPORTED;
+    }
+    if (M == 0) return MGAR_OK;
+    MGAR_REQUIRE(new_xyz && xyz && new_coords && point_indices && idx, "voxel_query: null pointer");
+    const size_t lds = (size_t)(nsample * VQ_ROW_STRIDE + VQ_THREADS) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)voxel_query_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (MGAR_MAX_NSAMPLE * VQ_ROW_STRIDE + VQ_THREADS) * (int)sizeof(int));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(voxel_query_kernel, dim3(ceil_div(M, VQ_THREADS)), dim3(VQ_THREADS), lds, (hipStream_t)stream,
+                       M, R1, R2, R3, nsample, radius * radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
+                       point_indices, idx);
+    return check_launch("voxel_query: launch failed");
+}

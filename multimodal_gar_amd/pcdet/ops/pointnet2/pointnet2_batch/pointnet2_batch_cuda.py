@@ -1,0 +1,62 @@
+"""Drop-in for the reference's compiled module ``pointnet2_batch_cuda``.
+
+Same function names and argument order as the pybind11 table in
+pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:10-24, so the reference's own
+``pointnet2_utils.py`` could import this module unchanged.  Each call forwards raw device
+pointers to the C ABI of libmgar_hip.so (include/mgar_ops.h); outputs are written in place
+into caller-allocated tensors, as in the reference.  Returns 1 like the reference wrappers.
+"""
+from ..... import _lib as L
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    L.call("mgar_ball_query_batch", b, n, m, float(radius), nsample, L.fptr(new_xyz), L.fptr(xyz), L.iptr(idx),
+           L.stream_of(xyz))
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    L.call("mgar_group_points_batch", b, c, n, npoints, nsample, L.fptr(points), L.iptr(idx), L.fptr(out),
+           L.stream_of(points))
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    L.call("mgar_group_points_grad_batch", b, c, n, npoints, nsample, L.fptr(grad_out), L.iptr(idx),
+           L.fptr(grad_points), L.stream_of(grad_out))
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    L.call("mgar_gather_points_batch", b, c, n, npoints, L.fptr(points), L.iptr(idx), L.fptr(out),
+           L.stream_of(points))
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    L.call("mgar_gather_points_grad_batch", b, c, n, npoints, L.fptr(grad_out), L.iptr(idx), L.fptr(grad_points),
+           L.stream_of(grad_out))
+    return 1
+
+
+def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    L.call("mgar_fps_batch", b, n, m, L.fptr(points), L.fptr(temp), L.iptr(idx), L.stream_of(points))
+    return 1
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    L.call("mgar_three_nn_batch", b, n, m, L.fptr(unknown), L.fptr(known), L.fptr(dist2), L.iptr(idx),
+           L.stream_of(unknown))
+    return 1
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    L.call("mgar_three_interpolate_batch", b, c, m, n, L.fptr(points), L.iptr(idx), L.fptr(weight), L.fptr(out),
+           L.stream_of(points))
+    return 1
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    L.call("mgar_three_interpolate_grad_batch", b, c, n, m, L.fptr(grad_out), L.iptr(idx), L.fptr(weight),
+           L.fptr(grad_points), L.stream_of(grad_out))
+    return 1

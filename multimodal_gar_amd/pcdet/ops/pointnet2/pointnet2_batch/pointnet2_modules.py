@@ -1,0 +1,103 @@
+"""Set-abstraction / feature-propagation modules on dense batches.
+
+Mirror of the reference's pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py
+(_PointnetSAModuleBase, PointnetSAModuleMSG, PointnetSAModule, PointnetFPModule): same
+constructor keywords, sub-module names (``groupers``, ``mlps``, ``mlp``) and parameter
+shapes, so reference state dicts load.
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import pointnet2_utils
+
+
+def shared_mlp_2d(spec: List[int]) -> nn.Sequential:
+    """[Conv2d 1x1 (no bias) -> BatchNorm2d -> ReLU] per consecutive channel pair."""
+    layers = []
+    for c_in, c_out in zip(spec[:-1], spec[1:]):
+        layers += [nn.Conv2d(c_in, c_out, kernel_size=1, bias=False), nn.BatchNorm2d(c_out), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+def pool_over_samples(x: torch.Tensor, method: str) -> torch.Tensor:
+    """(B, C, npoint, nsample) -> (B, C, npoint)."""
+    if method == 'max_pool':
+        return x.max(dim=3).values
+    if method == 'avg_pool':
+        return x.mean(dim=3)
+    raise NotImplementedError(method)
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.npoint = None
+        self.groupers = None
+        self.mlps = None
+        self.pool_method = 'max_pool'
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
+                new_xyz=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3), (B, sum_k mlps[k][-1], npoint).
+        Reference: pointnet2_modules.py:19-55."""
+        if new_xyz is None and self.npoint is not None:
+            picked = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+            xyz_t = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_t, picked).transpose(1, 2).contiguous()
+        per_scale = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped = grouper(xyz, new_xyz, features)          # (B, C', npoint, nsample)
+            per_scale.append(pool_over_samples(mlp(grouped), self.pool_method))
+        return new_xyz, torch.cat(per_scale, dim=1)
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Set abstraction with multi-scale grouping (reference pointnet2_modules.py:58-100).
+    As in the reference, ``mlps[i][0]`` is incremented IN PLACE by 3 when use_xyz."""
+
+    def __init__(self, *, npoint: int, radii: List[float], nsamples: List[int], mlps: List[List[int]],
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint = npoint
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
+                                 if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(shared_mlp_2d(spec))
+        self.pool_method = pool_method
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale set abstraction (reference pointnet2_modules.py:103-119)."""
+
+    def __init__(self, *, mlp: List[int], npoint: int = None, radius: float = None, nsample: int = None,
+                 bn: bool = True, use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__(mlps=[mlp], npoint=npoint, radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
+                         pool_method=pool_method)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: 3-NN inverse-distance interpolation + skip concat + shared MLP
+    (reference pointnet2_modules.py:122-170)."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        self.mlp = shared_mlp_2d(mlp)
+
+    def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
+                known_feats: torch.Tensor) -> torch.Tensor:
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            inv = 1.0 / (dist + 1e-8)
+            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        merged = spread if unknow_feats is None else torch.cat([spread, unknow_feats], dim=1)
+        return self.mlp(merged.unsqueeze(-1)).squeeze(-1)

@@ -1,0 +1,214 @@
+"""Dense-batch PointNet++ primitives, (B, N, 3) coordinates / (B, C, N) features.
+
+Mirror of the public surface of the reference's
+pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py (same class / function names,
+argument order, output shapes and dtypes, non-differentiable outputs), re-implemented on
+top of the HIP kernels behind ``pointnet2_batch_cuda`` (libmgar_hip.so).
+
+Ownership follows the reference: this layer allocates every output and scratch tensor
+(zero-filled idx for ball_query :218, 1e10-filled ``temp`` for FPS :26, zero-filled grad
+buffers :67,:146,:190); the native side only writes into them.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import pointnet2_batch_cuda as pointnet2
+
+
+def _new(like: torch.Tensor, shape, dtype, fill=None) -> torch.Tensor:
+    if fill is None:
+        return torch.empty(shape, dtype=dtype, device=like.device)
+    return torch.full(shape, fill, dtype=dtype, device=like.device)
+
+
+class FarthestPointSampling(Function):
+    """idx (B, npoint) int32 of an iterative farthest-point subset; first index is 0.
+    Reference: pointnet2_utils.py:10-33 -> sampling_gpu.cu:101-216."""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        assert xyz.is_contiguous()
+        batch, n_pts, _ = xyz.size()
+        idx = _new(xyz, (batch, npoint), torch.int32)
+        running_min = _new(xyz, (batch, n_pts), torch.float32, 1e10)
+        pointnet2.farthest_point_sampling_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad_idx=None):
+        return None, None
+
+
+farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
+
+
+class GatherOperation(Function):
+    """out[b, c, j] = features[b, c, idx[b, j]].  Reference: pointnet2_utils.py:39-73."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous() and idx.is_contiguous()
+        batch, npoint = idx.size()
+        _, chans, n_pts = features.size()
+        out = _new(features, (batch, chans, npoint), torch.float32)
+        pointnet2.gather_points_wrapper(batch, chans, n_pts, npoint, features, idx, out)
+        ctx.save_for_backward(idx)
+        ctx.src_shape = (chans, n_pts)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        chans, n_pts = ctx.src_shape
+        batch, npoint = idx.size()
+        grad_features = _new(grad_out, (batch, chans, n_pts), torch.float32, 0.0)
+        pointnet2.gather_points_grad_wrapper(batch, chans, n_pts, npoint, grad_out.contiguous(), idx, grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    """(dist, idx), both (B, n, 3): Euclidean distance to / index of the 3 nearest known
+    points.  The kernel returns squared distances; the sqrt is taken here like the
+    reference (pointnet2_utils.py:76-105)."""
+
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert unknown.is_contiguous() and known.is_contiguous()
+        batch, n_unknown, _ = unknown.size()
+        n_known = known.size(1)
+        dist2 = _new(unknown, (batch, n_unknown, 3), torch.float32)
+        idx = _new(unknown, (batch, n_unknown, 3), torch.int32)
+        pointnet2.three_nn_wrapper(batch, n_unknown, n_known, unknown, known, dist2, idx)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, grad_dist=None, grad_idx=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """out[b, c, i] = sum_k weight[b, i, k] * features[b, c, idx[b, i, k]].
+    Reference: pointnet2_utils.py:108-153."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
+        batch, chans, n_known = features.size()
+        n_unknown = idx.size(1)
+        out = _new(features, (batch, chans, n_unknown), torch.float32)
+        pointnet2.three_interpolate_wrapper(batch, chans, n_known, n_unknown, features, idx, weight, out)
+        ctx.save_for_backward(idx, weight)
+        ctx.n_known = n_known
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        batch, chans, n_unknown = grad_out.size()
+        grad_features = _new(grad_out, (batch, chans, ctx.n_known), torch.float32, 0.0)
+        pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, ctx.n_known, grad_out.contiguous(), idx,
+                                                 weight, grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    """out[b, c, p, s] = features[b, c, idx[b, p, s]].  Reference: pointnet2_utils.py:156-197."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous() and idx.is_contiguous()
+        batch, npoint, nsample = idx.size()
+        _, chans, n_pts = features.size()
+        out = _new(features, (batch, chans, npoint, nsample), torch.float32)
+        pointnet2.group_points_wrapper(batch, chans, n_pts, npoint, nsample, features, idx, out)
+        ctx.save_for_backward(idx)
+        ctx.n_pts = n_pts
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        batch, chans, npoint, nsample = grad_out.size()
+        grad_features = _new(grad_out, (batch, chans, ctx.n_pts), torch.float32, 0.0)
+        pointnet2.group_points_grad_wrapper(batch, chans, ctx.n_pts, npoint, nsample, grad_out.contiguous(), idx,
+                                            grad_features)
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    """idx (B, npoint, nsample) int32: the first nsample point indices (ascending) closer
+    than `radius` (strict) to each centre, padded with the first hit; all-zero row if the
+    ball is empty.  Reference: pointnet2_utils.py:200-228 -> ball_query_gpu.cu:15-51."""
+
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        assert new_xyz.is_contiguous() and xyz.is_contiguous()
+        batch, n_pts, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = _new(xyz, (batch, npoint, nsample), torch.int32, 0)
+        pointnet2.ball_query_wrapper(batch, n_pts, npoint, radius, nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, grad_idx=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class QueryAndGroup(nn.Module):
+    """ball_query -> group xyz (made relative to the centre) -> group features -> concat.
+    Output (B, 3 + C, npoint, nsample).  Reference: pointnet2_utils.py:231-264."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        rel_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B, 3, npoint, nsample)
+        rel_xyz = rel_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return rel_xyz
+        grouped = grouping_operation(features, idx)
+        return torch.cat([rel_xyz, grouped], dim=1) if self.use_xyz else grouped
+
+
+class GroupAll(nn.Module):
+    """One group holding every point: (B, 3 + C, 1, N).  Reference: pointnet2_utils.py:267-290."""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        all_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is None:
+            return all_xyz
+        all_feats = features.unsqueeze(2)
+        return torch.cat([all_xyz, all_feats], dim=1) if self.use_xyz else all_feats

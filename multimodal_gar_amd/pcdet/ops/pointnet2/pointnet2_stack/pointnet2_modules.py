@@ -1,0 +1,91 @@
+"""Set-abstraction / feature-propagation modules on stacked batches.
+
+Mirror of the reference's pcdet/ops/pointnet2/pointnet2_stack/pointnet2_modules.py:1-157
+(build_local_aggregation_module, StackSAModuleMSG, StackPointnetFPModule).  The
+VectorPool* modules (:160-470) are out of scope.
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+
+from . import pointnet2_utils
+
+
+def _shared_mlp_2d(spec):
+    layers = []
+    for c_in, c_out in zip(spec[:-1], spec[1:]):
+        layers += [nn.Conv2d(c_in, c_out, kernel_size=1, bias=False), nn.BatchNorm2d(c_out), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+def build_local_aggregation_module(input_channels, config):
+    name = config.get('NAME', 'StackSAModuleMSG')
+    if name != 'StackSAModuleMSG':
+        raise NotImplementedError('%s (vector-pool aggregation is out of scope)' % name)
+    mlps = config.MLPS
+    for k in range(len(mlps)):
+        mlps[k] = [input_channels] + mlps[k]
+    layer = StackSAModuleMSG(radii=config.POOL_RADIUS, nsamples=config.NSAMPLE, mlps=mlps, use_xyz=True,
+                             pool_method='max_pool')
+    return layer, sum(x[-1] for x in mlps)
+
+
+class StackSAModuleMSG(nn.Module):
+    """Reference: pointnet2_modules.py:30-112 (kaiming-normal convs, BN weight 1 / bias 0)."""
+
+    def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]],
+                 use_xyz: bool = True, pool_method='max_pool'):
+        super().__init__()
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz))
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(_shared_mlp_2d(spec))
+        self.pool_method = pool_method
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            if isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1.0)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
+        """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1]))."""
+        per_scale = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            grouped, _ = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)  # (M, C, nsample)
+            x = mlp(grouped.permute(1, 0, 2).unsqueeze(0))                                  # (1, C', M, nsample)
+            if self.pool_method == 'max_pool':
+                x = x.max(dim=3).values
+            elif self.pool_method == 'avg_pool':
+                x = x.mean(dim=3)
+            else:
+                raise NotImplementedError
+            per_scale.append(x.squeeze(0).permute(1, 0))                                    # (M, C')
+        return new_xyz, torch.cat(per_scale, dim=1)
+
+
+class StackPointnetFPModule(nn.Module):
+    """Reference: pointnet2_modules.py:115-157."""
+
+    def __init__(self, *, mlp: List[int]):
+        super().__init__()
+        self.mlp = _shared_mlp_2d(mlp)
+
+    def forward(self, unknown, unknown_batch_cnt, known, known_batch_cnt, unknown_feats=None, known_feats=None):
+        dist, idx = pointnet2_utils.three_nn(unknown, unknown_batch_cnt, known, known_batch_cnt)
+        inv = 1.0 / (dist + 1e-8)
+        weight = inv / torch.sum(inv, dim=-1, keepdim=True)
+        spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        merged = spread if unknown_feats is None else torch.cat([spread, unknown_feats], dim=1)
+        x = self.mlp(merged.permute(1, 0)[None, :, :, None])           # (1, C, N, 1)
+        return x.squeeze(0).squeeze(-1).permute(1, 0)

@@ -1,0 +1,60 @@
+"""Drop-in for the reference's compiled module ``pointnet2_stack_cuda``.
+
+Same function names and argument order as the pybind11 table in
+pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:12-31 (the four vector-pool
+entries are out of scope: PV-RCNN++ only, unreachable from MGAR-net -- SURVEY.md section 2.2).
+"""
+from ..... import _lib as L
+
+
+def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+    L.call("mgar_ball_query_stack", B, M, float(radius), nsample, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt),
+           L.fptr(xyz), L.iptr(xyz_batch_cnt), L.iptr(idx), L.stream_of(xyz))
+    return 1
+
+
+def voxel_query_wrapper(M, R1, R2, R3, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
+                        point_indices, idx):
+    L.call("mgar_voxel_query_stack", M, R1, R2, R3, nsample, float(radius), z_range, y_range, x_range,
+           L.fptr(new_xyz), L.fptr(xyz), L.iptr(new_coords), L.iptr(point_indices), L.iptr(idx), L.stream_of(xyz))
+    return 1
+
+
+def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
+    # pointnet2_stack re-exports the dense-batch FPS (pointnet2_stack/src/sampling_gpu.cu:25-140)
+    L.call("mgar_fps_batch", b, n, m, L.fptr(points), L.fptr(temp), L.iptr(idx), L.stream_of(points))
+    return 1
+
+
+def stack_farthest_point_sampling_wrapper(points, temp, xyz_batch_cnt, idx, num_sampled_points):
+    L.call("mgar_fps_stack", xyz_batch_cnt.shape[0], points.shape[0], L.fptr(points), L.fptr(temp),
+           L.iptr(xyz_batch_cnt), L.iptr(idx), L.iptr(num_sampled_points), L.stream_of(points))
+    return 1
+
+
+def group_points_wrapper(B, M, C, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):
+    L.call("mgar_group_points_stack", B, M, C, nsample, L.fptr(features), L.iptr(features_batch_cnt), L.iptr(idx),
+           L.iptr(idx_batch_cnt), L.fptr(out), L.stream_of(features))
+    return 1
+
+
+def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+    L.call("mgar_group_points_grad_stack", B, M, C, N, nsample, L.fptr(grad_out), L.iptr(idx),
+           L.iptr(idx_batch_cnt), L.iptr(features_batch_cnt), L.fptr(grad_features), L.stream_of(grad_out))
+    return 1
+
+
+def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+    L.call("mgar_three_nn_stack", unknown_batch_cnt.shape[0], unknown.shape[0], known.shape[0], L.fptr(unknown),
+           L.iptr(unknown_batch_cnt), L.fptr(known), L.iptr(known_batch_cnt), L.fptr(dist2), L.iptr(idx),
+           L.stream_of(unknown))
+
+
+def three_interpolate_wrapper(features, idx, weight, out):
+    L.call("mgar_three_interpolate_stack", idx.shape[0], features.shape[1], L.fptr(features), L.iptr(idx),
+           L.fptr(weight), L.fptr(out), L.stream_of(features))
+
+
+def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
+    L.call("mgar_three_interpolate_grad_stack", idx.shape[0], grad_out.shape[1], L.fptr(grad_out), L.iptr(idx),
+           L.fptr(weight), L.fptr(grad_features), L.stream_of(grad_out))

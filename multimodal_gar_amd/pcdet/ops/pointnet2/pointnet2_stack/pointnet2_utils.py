@@ -1,0 +1,210 @@
+"""Stacked-batch PointNet++ primitives: (N1+N2+..., 3|C) rows plus per-sample counts.
+
+Mirror of the public surface of the reference's
+pcdet/ops/pointnet2/pointnet2_stack/pointnet2_utils.py:1-303 (ball_query, grouping_operation,
+QueryAndGroup, farthest_point_sample, stack_farthest_point_sample, three_nn,
+three_interpolate), on top of the HIP kernels behind ``pointnet2_stack_cuda``.
+The vector-pool family (:306-457) is out of scope (PV-RCNN++ only).
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import pointnet2_stack_cuda as pointnet2
+
+
+def _empty(like, shape, dtype):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+class BallQuery(Function):
+    """Returns (idx (M, nsample) int32 LOCAL indices, empty_ball_mask (M) bool).
+    The kernel marks an empty ball with idx[row, 0] == -1; such rows are reported in the
+    mask and reset to 0 (reference pointnet2_utils.py:33-37)."""
+
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor,
+                new_xyz: torch.Tensor, new_xyz_batch_cnt):
+        assert new_xyz.is_contiguous() and new_xyz_batch_cnt.is_contiguous()
+        assert xyz.is_contiguous() and xyz_batch_cnt.is_contiguous()
+        n_samples = xyz_batch_cnt.shape[0]
+        n_query = new_xyz.shape[0]
+        idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz,
+                                     xyz_batch_cnt, idx)
+        empty_ball_mask = idx[:, 0] == -1
+        idx[empty_ball_mask] = 0
+        ctx.mark_non_differentiable(idx, empty_ball_mask)
+        return idx, empty_ball_mask
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class GroupingOperation(Function):
+    """out[m, c, s] = features[start(sample of m) + idx[m, s], c]  -> (M, C, nsample).
+    Reference: pointnet2_utils.py:52-106."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, features_batch_cnt: torch.Tensor,
+                idx: torch.Tensor, idx_batch_cnt: torch.Tensor):
+        assert features.is_contiguous() and features_batch_cnt.is_contiguous()
+        assert idx.is_contiguous() and idx_batch_cnt.is_contiguous()
+        assert features.shape[0] == features_batch_cnt.sum(), \
+            'features: %s, features_batch_cnt: %s' % (str(features.shape), str(features_batch_cnt))
+        assert idx.shape[0] == idx_batch_cnt.sum(), \
+            'idx: %s, idx_batch_cnt: %s' % (str(idx.shape), str(idx_batch_cnt))
+        n_query, nsample = idx.size()
+        n_rows, chans = features.size()
+        n_samples = idx_batch_cnt.shape[0]
+        out = _empty(features, (n_query, chans, nsample), torch.float32)
+        pointnet2.group_points_wrapper(n_samples, n_query, chans, nsample, features, features_batch_cnt, idx,
+                                       idx_batch_cnt, out)
+        ctx.save_for_backward(idx, features_batch_cnt, idx_batch_cnt)
+        ctx.dims = (n_samples, n_rows)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, features_batch_cnt, idx_batch_cnt = ctx.saved_tensors
+        n_samples, n_rows = ctx.dims
+        n_query, chans, nsample = grad_out.size()
+        grad_features = torch.zeros((n_rows, chans), dtype=torch.float32, device=grad_out.device)
+        pointnet2.group_points_grad_wrapper(n_samples, n_query, chans, n_rows, nsample, grad_out.contiguous(), idx,
+                                            idx_batch_cnt, features_batch_cnt, grad_features)
+        return grad_features, None, None, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class QueryAndGroup(nn.Module):
+    """Returns (new_features (M, 3 + C, nsample), idx).  Relative xyz and features of empty
+    balls are zeroed.  Reference: pointnet2_utils.py:112-159."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, xyz_batch_cnt: torch.Tensor,
+                new_xyz: torch.Tensor, new_xyz_batch_cnt: torch.Tensor,
+                features: torch.Tensor = None):
+        assert xyz.shape[0] == xyz_batch_cnt.sum(), \
+            'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
+        assert new_xyz.shape[0] == new_xyz_batch_cnt.sum(), \
+            'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
+        idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
+        keep = (~empty).view(-1, 1, 1).to(xyz.dtype)
+        rel_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)  # (M, 3, nsample)
+        rel_xyz = (rel_xyz - new_xyz.unsqueeze(-1)) * keep
+        if features is None:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            return rel_xyz, idx
+        grouped = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt) * keep
+        new_features = torch.cat([rel_xyz, grouped], dim=1) if self.use_xyz else grouped
+        return new_features, idx
+
+
+class FarthestPointSampling(Function):
+    """Dense-batch FPS re-exported by the stack package (reference pointnet2_utils.py:162-188)."""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int):
+        assert xyz.is_contiguous()
+        batch, n_pts, _ = xyz.size()
+        idx = _empty(xyz, (batch, npoint), torch.int32)
+        running_min = torch.full((batch, n_pts), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.farthest_point_sampling_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
+
+
+class StackFarthestPointSampling(Function):
+    """FPS per stacked segment; returns GLOBAL row ids, concatenated (sum of npoint).
+    Reference: pointnet2_utils.py:191-225 -> sampling_gpu.cu:188-348."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, npoint):
+        assert xyz.is_contiguous() and xyz.shape[1] == 3
+        n_samples = len(xyz_batch_cnt)
+        if not isinstance(npoint, torch.Tensor):
+            if not isinstance(npoint, list):
+                npoint = [npoint] * n_samples
+            npoint = torch.tensor(npoint, device=xyz.device).int()
+        npoint = npoint.to(device=xyz.device, dtype=torch.int32).contiguous()
+        running_min = torch.full((xyz.shape[0],), 1e10, dtype=torch.float32, device=xyz.device)
+        idx = _empty(xyz, (int(npoint.sum().item()),), torch.int32)
+        pointnet2.stack_farthest_point_sampling_wrapper(xyz, running_min, xyz_batch_cnt.int().contiguous(), idx,
+                                                        npoint)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
+
+
+stack_farthest_point_sample = StackFarthestPointSampling.apply
+
+
+class ThreeNN(Function):
+    """(dist (N, 3), idx (N, 3) GLOBAL rows of `known`).  Reference: pointnet2_utils.py:228-258."""
+
+    @staticmethod
+    def forward(ctx, unknown, unknown_batch_cnt, known, known_batch_cnt):
+        assert unknown.dim() == 2 and unknown.shape[1] == 3
+        assert known.dim() == 2 and known.shape[1] == 3
+        assert len(unknown_batch_cnt) == len(known_batch_cnt)
+        dist2 = unknown.new_zeros(unknown.shape)
+        idx = torch.zeros(unknown.shape, dtype=torch.int32, device=unknown.device)
+        pointnet2.three_nn_wrapper(unknown.contiguous(), unknown_batch_cnt.contiguous(), known.contiguous(),
+                                   known_batch_cnt.contiguous(), dist2, idx)
+        dist = torch.sqrt(dist2)
+        ctx.mark_non_differentiable(dist, idx)
+        return dist, idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """out[i, c] = sum_k weight[i, k] * features[idx[i, k], c]  -> (N, C).
+    Reference: pointnet2_utils.py:264-300."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor):
+        assert idx.shape[0] == weight.shape[0] and idx.shape[1] == weight.shape[1] == 3
+        idx, weight = idx.contiguous(), weight.contiguous()
+        ctx.save_for_backward(idx, weight)
+        ctx.n_known = features.shape[0]
+        out = features.new_zeros((idx.shape[0], features.shape[1]))
+        pointnet2.three_interpolate_wrapper(features.contiguous(), idx, weight, out)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight = ctx.saved_tensors
+        grad_features = grad_out.new_zeros((ctx.n_known, grad_out.shape[1]))
+        pointnet2.three_interpolate_grad_wrapper(grad_out.contiguous(), idx, weight, grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply

@@ -1,0 +1,306 @@
+"""numpy front-end of the C oracle (oracle/mgar_oracle.c) + float64 numpy restatements of
+the third-party ops the reference calls (torchvision roi_align / generalized_box_iou,
+torch_geometric GATv2Conv, torchmetrics pairwise_*) and of the DAFM attention core.
+
+TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg may import this module -- as the checker or the timed baseline.
+Parity status: "parity unpinned" by reference tests (the reference has none); see
+mgar_oracle.c header and DESIGN.md.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmgar_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mgar_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s", "libmgar_oracle.so"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _f(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _cf(x):
+    return ctypes.c_float(float(x))
+
+
+def set_threads(t):
+    lib().orc_set_threads(int(t))
+
+
+def opt_n_threads(n):
+    return int(lib().orc_opt_n_threads(int(n)))
+
+
+# ------------------------------ batch layout ------------------------------
+def ball_query_batch(radius, nsample, xyz, new_xyz):
+    xyz, px = _f(xyz); new_xyz, pq = _f(new_xyz)
+    b, n, _ = xyz.shape
+    m = new_xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    lib().orc_ball_query_batch(b, n, m, _cf(radius), nsample, pq, px, idx.ctypes.data_as(ctypes.c_void_p))
+    return idx
+
+
+def fps_batch(xyz, npoint, temp=None):
+    xyz, px = _f(xyz)
+    b, n, _ = xyz.shape
+    temp = np.full((b, n), 1e10, np.float32) if temp is None else np.ascontiguousarray(temp, np.float32).copy()
+    idx = np.zeros((b, npoint), np.int32)
+    lib().orc_fps_batch(b, n, npoint, px, temp.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p))
+    return idx, temp
+
+
+def gather_points(points, idx):
+    points, pp = _f(points); idx, pi = _i(idx)
+    b, c, n = points.shape
+    m = idx.shape[1]
+    out = np.zeros((b, c, m), np.float32)
+    lib().orc_gather_points(b, c, n, m, pp, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx)
+    b, c, m = grad_out.shape
+    g = np.zeros((b, c, n), np.float32)
+    lib().orc_gather_points_grad(b, c, n, m, pg, pi, g.ctypes.data_as(ctypes.c_void_p))
+    return g
+
+
+def group_points_batch(points, idx):
+    points, pp = _f(points); idx, pi = _i(idx)
+    b, c, n = points.shape
+    _, npnt, ns = idx.shape
+    out = np.zeros((b, c, npnt, ns), np.float32)
+    lib().orc_group_points_batch(b, c, n, npnt, ns, pp, pi, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def group_points_grad_batch(grad_out, idx, n):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx)
+    b, c, npnt, ns = grad_out.shape
+    g = np.zeros((b, c, n), np.float32)
+    lib().orc_group_points_grad_batch(b, c, n, npnt, ns, pg, pi, g.ctypes.data_as(ctypes.c_void_p))
+    return g
+
+
+def three_nn_batch(unknown, known):
+    unknown, pu = _f(unknown); known, pk = _f(known)
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.zeros((b, n, 3), np.float32); idx = np.zeros((b, n, 3), np.int32)
+    lib().orc_three_nn_batch(b, n, m, pu, pk, d2.ctypes.data_as(ctypes.c_void_p), idx.ctypes.data_as(ctypes.c_void_p))
+    return d2, idx
+
+
+def three_interpolate_batch(points, idx, weight):
+    points, pp = _f(points); idx, pi = _i(idx); weight, pw = _f(weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    out = np.zeros((b, c, n), np.float32)
+    lib().orc_three_interpolate_batch(b, c, m, n, pp, pi, pw, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def three_interpolate_grad_batch(grad_out, idx, weight, m):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx); weight, pw = _f(weight)
+    b, c, n = grad_out.shape
+    g = np.zeros((b, c, m), np.float32)
+    lib().orc_three_interpolate_grad_batch(b, c, n, m, pg, pi, pw, g.ctypes.data_as(ctypes.c_void_p))
+    return g
+
+
+# ------------------------------ stack layout ------------------------------
+def ball_query_stack(radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt):
+    """Returns the RAW kernel output (idx[row,0] == -1 marks an empty ball)."""
+    xyz, px = _f(xyz); new_xyz, pq = _f(new_xyz)
+    xc, pxc = _i(xyz_batch_cnt); qc, pqc = _i(new_xyz_batch_cnt)
+    M = new_xyz.shape[0]
+    idx = np.zeros((M, nsample), np.int32)
+    lib().orc_ball_query_stack(len(xc), M, _cf(radius), nsample, pq, pqc, px, pxc, idx.ctypes.data_as(ctypes.c_void_p))
+    return idx
+
+
+def fps_stack(xyz, xyz_batch_cnt, npoints, temp=None):
+    xyz, px = _f(xyz); xc, pxc = _i(xyz_batch_cnt); npnt, pn = _i(npoints)
+    temp = np.full((xyz.shape[0],), 1e10, np.float32) if temp is None else np.ascontiguousarray(temp, np.float32).copy()
+    idx = np.zeros((int(npnt.sum()),), np.int32)
+    lib().orc_fps_stack(len(xc), px, temp.ctypes.data_as(ctypes.c_void_p), pxc, idx.ctypes.data_as(ctypes.c_void_p), pn)
+    return idx, temp
+
+
+def group_points_stack(features, features_batch_cnt, idx, idx_batch_cnt):
+    features, pf = _f(features); idx, pi = _i(idx)
+    fc, pfc = _i(features_batch_cnt); ic, pic = _i(idx_batch_cnt)
+    M, ns = idx.shape
+    C = features.shape[1]
+    out = np.zeros((M, C, ns), np.float32)
+    lib().orc_group_points_stack(len(ic), M, C, ns, pf, pfc, pi, pic, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def group_points_grad_stack(grad_out, idx, idx_batch_cnt, features_batch_cnt, N):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx)
+    fc, pfc = _i(features_batch_cnt); ic, pic = _i(idx_batch_cnt)
+    M, C, ns = grad_out.shape
+    g = np.zeros((N, C), np.float32)
+    lib().orc_group_points_grad_stack(len(ic), M, C, N, ns, pg, pi, pic, pfc, g.ctypes.data_as(ctypes.c_void_p))
+    return g
+
+
+def three_nn_stack(unknown, unknown_batch_cnt, known, known_batch_cnt):
+    unknown, pu = _f(unknown); known, pk = _f(known)
+    uc, puc = _i(unknown_batch_cnt); kc, pkc = _i(known_batch_cnt)
+    N = unknown.shape[0]
+    d2 = np.zeros((N, 3), np.float32); idx = np.zeros((N, 3), np.int32)
+    lib().orc_three_nn_stack(len(uc), N, pu, puc, pk, pkc, d2.ctypes.data_as(ctypes.c_void_p),
+                             idx.ctypes.data_as(ctypes.c_void_p))
+    return d2, idx
+
+
+def three_interpolate_stack(features, idx, weight):
+    features, pf = _f(features); idx, pi = _i(idx); weight, pw = _f(weight)
+    N, C = idx.shape[0], features.shape[1]
+    out = np.zeros((N, C), np.float32)
+    lib().orc_three_interpolate_stack(N, C, pf, pi, pw, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def three_interpolate_grad_stack(grad_out, idx, weight, M):
+    grad_out, pg = _f(grad_out); idx, pi = _i(idx); weight, pw = _f(weight)
+    N, C = grad_out.shape
+    g = np.zeros((M, C), np.float32)
+    lib().orc_three_interpolate_grad_stack(N, C, pg, pi, pw, g.ctypes.data_as(ctypes.c_void_p))
+    return g
+
+
+def voxel_query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """RAW kernel output (idx[row,0] == -1 marks an empty neighbourhood)."""
+    xyz, px = _f(xyz); new_xyz, pq = _f(new_xyz)
+    nc, pnc = _i(new_coords); pin, ppi = _i(point_indices)
+    M = nc.shape[0]
+    B, R1, R2, R3 = pin.shape
+    z_r, y_r, x_r = (int(v) for v in max_range)
+    idx = np.zeros((M, nsample), np.int32)
+    lib().orc_voxel_query(M, R1, R2, R3, nsample, _cf(radius), z_r, y_r, x_r, pq, px, pnc, ppi,
+                          idx.ctypes.data_as(ctypes.c_void_p))
+    return idx
+
+
+def roi_align(inp, rois, output_size, spatial_scale, sampling_ratio=-1, aligned=False):
+    inp, pi_ = _f(inp); rois, pr = _f(rois)
+    N, C, H, W = inp.shape
+    K = rois.shape[0]
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    out = np.zeros((K, C, ph, pw), np.float32)
+    lib().orc_roi_align_fwd(pi_, N, C, H, W, pr, K, ph, pw, _cf(spatial_scale), int(sampling_ratio), int(aligned),
+                            out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+# ------------------ float64 numpy restatements (third-party arithmetic) ------------------
+def generalized_box_iou(a, b):
+    """torchvision.ops.generalized_box_iou: IoU - (C - U)/C on xyxy boxes (call sites
+    model/gat_model.py:1350,1470,1519)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = np.maximum(a[:, None, :2], b[None, :, :2]); rb = np.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = np.clip(rb - lt, 0, None)
+    inter = wh[..., 0] * wh[..., 1]
+    union = area_a[:, None] + area_b[None, :] - inter
+    iou = inter / union
+    lti = np.minimum(a[:, None, :2], b[None, :, :2]); rbi = np.maximum(a[:, None, 2:], b[None, :, 2:])
+    whi = np.clip(rbi - lti, 0, None)
+    areai = whi[..., 0] * whi[..., 1]
+    return iou - (areai - union) / areai
+
+
+def pairwise_euclidean_distance(x, zero_diagonal=True):
+    """torchmetrics.functional.pairwise_euclidean_distance(x): sqrt(|x|^2+|y|^2-2xy) (call
+    sites model/gat_model.py:1471,1520)."""
+    x = np.asarray(x, np.float64)
+    d = np.sqrt(np.clip((x * x).sum(1)[:, None] + (x * x).sum(1)[None, :] - 2 * x @ x.T, 0, None))
+    if zero_diagonal:
+        np.fill_diagonal(d, 0)
+    return d
+
+
+def pairwise_cosine_similarity(x, zero_diagonal=False):
+    """torchmetrics.functional.pairwise_cosine_similarity (call site model/gat_model.py:1335)."""
+    x = np.asarray(x, np.float64)
+    xn = x / np.linalg.norm(x, axis=1, keepdims=True)
+    s = xn @ xn.T
+    if zero_diagonal:
+        np.fill_diagonal(s, 0)
+    return s
+
+
+def softmax(x, axis):
+    x = x - x.max(axis=axis, keepdims=True)
+    e = np.exp(x)
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def dafm_attention(q, k, v, de, sigma, scale):
+    """model/gat_model.py:487-491: E = softmax(-De/sigma, 1); Att = softmax((QK^T * E)*scale, 1); Att V."""
+    q, k, v, de = (np.asarray(t, np.float64) for t in (q, k, v, de))
+    e = softmax(-(de / sigma), 1)
+    att = softmax((q @ k.T) * e * scale, 1)
+    return att @ v, att
+
+
+def gatv2(x, edge_index, w_l, b_l, w_r, b_r, att, bias, heads, out_ch, slope=0.2, concat=False,
+          add_self_loops=True):
+    """torch_geometric.nn.GATv2Conv forward in eval mode (no dropout), float64.
+    x_l = W_l x + b_l, x_r = W_r x + b_r; e_ij = att_h . leaky_relu(x_l[j] + x_r[i]);
+    alpha = softmax over incoming edges j -> i (self loops added); out_i = sum_j alpha x_l[j];
+    mean over heads when concat=False; + bias.  edge_index[0] = source j, [1] = target i."""
+    x = np.asarray(x, np.float64)
+    n = x.shape[0]
+    ei = np.asarray(edge_index, np.int64)
+    if add_self_loops:
+        keep = ei[0] != ei[1]
+        ei = np.concatenate([ei[:, keep], np.stack([np.arange(n), np.arange(n)])], 1)
+    xl = (x @ np.asarray(w_l, np.float64).T + np.asarray(b_l, np.float64)).reshape(n, heads, out_ch)
+    xr = (x @ np.asarray(w_r, np.float64).T + np.asarray(b_r, np.float64)).reshape(n, heads, out_ch)
+    a = np.asarray(att, np.float64).reshape(heads, out_ch)
+    src, dst = ei
+    z = xl[src] + xr[dst]
+    z = np.where(z > 0, z, slope * z)
+    e = (z * a[None]).sum(-1)  # (E, H)
+    out = np.zeros((n, heads, out_ch))
+    for i in range(n):
+        m = dst == i
+        if not m.any():
+            continue
+        al = softmax(e[m], 0)  # (deg, H)
+        out[i] = (al[:, :, None] * xl[src[m]]).sum(0)
+    out = out.reshape(n, heads * out_ch) if concat else out.mean(1)
+    return out + np.asarray(bias, np.float64)
