@@ -171,15 +171,18 @@ int mgar_dafm_attn_bwd(int S, int total_rows, int D, const int *scene_off, const
  *   e_ij   = att_h . leaky_relu(xl_j + xr_i, slope)
  *   alpha  = softmax_j(e_ij)          (saved, (E,H))
  *   out_i  = sum_j alpha_ij * xl_j    (n_nodes, H*C)
+ * edge_scale (E,H), may be NULL: multiplies alpha in the aggregation only (PyG applies
+ * dropout to alpha in training mode: pass mask/(1-p)); alpha is saved un-scaled.
  * bwd: grad_xl and grad_att are ACCUMULATED into (caller zero-fills them); grad_xr is
  * fully written.
  */
 /* C must be a multiple of 64 (lanes run along the channel axis). */
 int mgar_gatv2_fwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
-                   const float *xr, const float *att, float slope, float *alpha, float *out, void *stream);
+                   const float *xr, const float *att, float slope, const float *edge_scale, float *alpha,
+                   float *out, void *stream);
 int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
-                   const float *xr, const float *att, float slope, const float *alpha, const float *grad_out,
-                   float *grad_xl, float *grad_xr, float *grad_att, void *stream);
+                   const float *xr, const float *att, float slope, const float *edge_scale, const float *alpha,
+                   const float *grad_out, float *grad_xl, float *grad_xr, float *grad_att, void *stream);
 
 #ifdef __cplusplus
 }

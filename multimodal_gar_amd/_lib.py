@@ -44,8 +44,8 @@ _PROTOS = {
     "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_dafm_attn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
     "mgar_dafm_attn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
-    "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P],
-    "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P],
+    "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P],
+    "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
 }
 
 _fns = {}

@@ -31,7 +31,8 @@ template <int CPL>
 __global__ __launch_bounds__(256) void gatv2_fwd_kernel(int n_nodes, int H, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const float *__restrict__ xl,
                                                         const float *__restrict__ xr, const float *__restrict__ att,
-                                                        float slope, float *__restrict__ alpha, float *__restrict__ out) {
+                                                        float slope, const float *__restrict__ edge_scale,
+                                                        float *__restrict__ alpha, float *__restrict__ out) {
     constexpr int C = CPL * kWave;
     const int lane = threadIdx.x & 63;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -70,8 +71,9 @@ __global__ __launch_bounds__(256) void gatv2_fwd_kernel(int n_nodes, int H, cons
         const int j = col[e];
         const float al = __expf(ld_l2(alpha + (size_t)e * H + h) - emax) * inv;
         const float *lj = xl + ((size_t)j * H + h) * C;
+        const float am = edge_scale ? al * edge_scale[(size_t)e * H + h] : al;
 #pragma unroll
-        for (int u = 0; u < CPL; ++u) acc[u] += al * lj[u * kWave + lane];
+        for (int u = 0; u < CPL; ++u) acc[u] += am * lj[u * kWave + lane];
         if (lane == 0) st_l2(alpha + (size_t)e * H + h, al);
     }
 #pragma unroll
@@ -87,7 +89,8 @@ template <int CPL>
 __global__ __launch_bounds__(256) void gatv2_bwd_kernel(int n_nodes, int H, const int *__restrict__ rowptr,
                                                         const int *__restrict__ col, const float *__restrict__ xl,
                                                         const float *__restrict__ xr, const float *__restrict__ att,
-                                                        float slope, const float *__restrict__ alpha,
+                                                        float slope, const float *__restrict__ edge_scale,
+                                                        const float *__restrict__ alpha,
                                                         const float *__restrict__ grad_out, float *__restrict__ grad_xl,
                                                         float *__restrict__ grad_xr, float *__restrict__ grad_att) {
     constexpr int C = CPL * kWave;
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(256) void gatv2_bwd_kernel(int n_nodes, int H, cons
         float part = 0.f;
 #pragma unroll
         for (int u = 0; u < CPL; ++u) part += go[u] * lj[u * kWave + lane];
-        s += alpha[(size_t)e * H + h] * wave_sum(part);
+        const float m = edge_scale ? edge_scale[(size_t)e * H + h] : 1.f;
+        s += alpha[(size_t)e * H + h] * m * wave_sum(part);
     }
     for (int e = e0; e < e1; ++e) {
         const int j = col[e];
@@ -122,14 +126,15 @@ __global__ __launch_bounds__(256) void gatv2_bwd_kernel(int n_nodes, int H, cons
 #pragma unroll
         for (int u = 0; u < CPL; ++u) { lv[u] = lj[u * kWave + lane]; part += go[u] * lv[u]; }
         const float al = alpha[(size_t)e * H + h];
-        const float de = al * (wave_sum(part) - s);
+        const float m = edge_scale ? edge_scale[(size_t)e * H + h] : 1.f;
+        const float de = al * (m * wave_sum(part) - s);
 #pragma unroll
         for (int u = 0; u < CPL; ++u) {
             const float z = lv[u] + r[u];
             const float dz = de * a[u] * (z > 0.f ? 1.f : slope);
             gxr[u] += dz;
             gatt[u] += de * (z > 0.f ? z : slope * z);
-            atomicAdd(gj + u * kWave + lane, al * go[u] + dz);
+            atomicAdd(gj + u * kWave + lane, al * m * go[u] + dz);
         }
     }
 #pragma unroll
@@ -155,21 +160,23 @@ using namespace mgar;
 
 extern "C" __attribute__((visibility("default"))) int mgar_gatv2_fwd(int n_nodes, int H, int C, const int *rowptr,
                                                                     const int *col, const float *xl, const float *xr,
-                                                                    const float *att, float slope, float *alpha,
-                                                                    float *out, void *stream) {
+                                                                    const float *att, float slope,
+                                                                    const float *edge_scale, float *alpha, float *out,
+                                                                    void *stream) {
     MGAR_REQUIRE(n_nodes >= 0 && H > 0 && C > 0, "gatv2_fwd: bad sizes");
     if (n_nodes == 0) return MGAR_OK;
     MGAR_REQUIRE(rowptr && col && xl && xr && att && alpha && out, "gatv2_fwd: null pointer");
     if (C % 64 != 0) { set_error("gatv2_fwd: C must be a multiple of 64"); return MGAR_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ceil_div((long long)n_nodes * H, 4));
-    GAT_DISPATCH(gatv2_fwd_kernel, n_nodes, H, rowptr, col, xl, xr, att, slope, alpha, out);
+    GAT_DISPATCH(gatv2_fwd_kernel, n_nodes, H, rowptr, col, xl, xr, att, slope, edge_scale, alpha, out);
     return check_launch("gatv2_fwd: launch failed");
 }
 
 extern "C" __attribute__((visibility("default"))) int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr,
                                                                     const int *col, const float *xl, const float *xr,
-                                                                    const float *att, float slope, const float *alpha,
+                                                                    const float *att, float slope,
+                                                                    const float *edge_scale, const float *alpha,
                                                                     const float *grad_out, float *grad_xl, float *grad_xr,
                                                                     float *grad_att, void *stream) {
     MGAR_REQUIRE(n_nodes >= 0 && H > 0 && C > 0, "gatv2_bwd: bad sizes");
@@ -179,6 +186,6 @@ extern "C" __attribute__((visibility("default"))) int mgar_gatv2_bwd(int n_nodes
     if (C % 64 != 0) { set_error("gatv2_bwd: C must be a multiple of 64"); return MGAR_EUNSUPPORTED; }
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(ceil_div((long long)n_nodes * H, 4));
-    GAT_DISPATCH(gatv2_bwd_kernel, n_nodes, H, rowptr, col, xl, xr, att, slope, alpha, grad_out, grad_xl, grad_xr, grad_att);
+    GAT_DISPATCH(gatv2_bwd_kernel, n_nodes, H, rowptr, col, xl, xr, att, slope, edge_scale, alpha, grad_out, grad_xl, grad_xr, grad_att);
     return check_launch("gatv2_bwd: launch failed");
 }

@@ -1,0 +1,142 @@
+"""GPU parity tests for the ops that are third-party in the reference (RoIAlign, GATv2) and for
+the fused DAFM attention core: values and gradients against float64 torch references, and
+against the C / numpy oracle.  Tolerance 1e-4 relative (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+import torch_refs as R
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+def close(a, b, rtol=RTOL, atol=1e-5):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, "max err %g vs scale %g" % (err, scale)
+
+
+def test_roi_align_fwd_vs_oracle_and_ref(oracle):
+    from multimodal_gar_amd.vision_ops import roi_align
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((2, 7, 12, 20)).astype(np.float32)
+    rois = np.array([[0, 3.0, 5.0, 150.0, 100.0], [1, 0.0, 0.0, 319.0, 191.0], [0, 200.0, 40.0, 210.0, 44.0],
+                     [1, 0.0, 0.0, 0.0, 0.0], [0, 300.0, 180.0, 330.0, 200.0], [1, -20.0, -10.0, 50.0, 60.0]], np.float32)
+    out = roi_align(torch.from_numpy(feat).cuda(), torch.from_numpy(rois).cuda(), 5, spatial_scale=1 / 16.0)
+    want = oracle.roi_align(feat, rois, 5, 1 / 16.0)
+    close(out, torch.from_numpy(want))
+    ref = R.roi_align_ref(torch.from_numpy(feat), torch.from_numpy(rois), 5, 1 / 16.0)
+    close(out, ref)
+    out2 = roi_align(torch.from_numpy(feat).cuda(), torch.from_numpy(rois).cuda(), 3, spatial_scale=0.0625, sampling_ratio=2,
+                     aligned=True)
+    close(out2, R.roi_align_ref(torch.from_numpy(feat), torch.from_numpy(rois), 3, 0.0625, 2, True))
+
+
+def test_roi_align_list_form_and_backward():
+    from multimodal_gar_amd.vision_ops import roi_align
+    torch.manual_seed(0)
+    feat = torch.randn(2, 5, 9, 14, dtype=torch.float32)
+    boxes = [torch.tensor([[4.0, 4.0, 100.0, 90.0], [0.0, 0.0, 0.0, 0.0]]), torch.tensor([[30.0, 10.0, 200.0, 120.0]])]
+    f = feat.cuda().requires_grad_(True)
+    out = roi_align(f, [b.cuda() for b in boxes], output_size=5, spatial_scale=14 / 224.0)
+    assert out.shape == (3, 5, 5, 5)
+    g = torch.randn_like(out)
+    out.backward(g)
+    fr = feat.double().requires_grad_(True)
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), b], 1) for i, b in enumerate(boxes)])
+    ref = R.roi_align_ref(fr, rois, 5, 14 / 224.0)
+    ref.backward(g.double().cpu())
+    close(out, ref)
+    close(f.grad, fr.grad)
+
+
+@pytest.mark.parametrize("counts,D", [([32] * 5, 512), ([8, 2, 33, 100, 128], 512), ([3], 64)])
+def test_dafm_attention_fwd_bwd(oracle, counts, D):
+    from multimodal_gar_amd.dafm_ops import dafm_attention, scene_offsets
+    torch.manual_seed(1)
+    rows = sum(counts)
+    q = (torch.randn(rows, D) * 0.5).cuda().requires_grad_(True)
+    k = (torch.randn(rows, D) * 0.5).cuda().requires_grad_(True)
+    v = torch.randn(rows, D).cuda().requires_grad_(True)
+    des = [torch.rand(n, n) * 20 for n in counts]
+    for d in des:
+        d.fill_diagonal_(0)
+    de_flat = torch.cat([d.reshape(-1) for d in des]).cuda()
+    so, do = scene_offsets(counts, "cuda")
+    scale = 1.0 / D ** 0.5
+    out, att = dafm_attention(q, k, v, de_flat, so, do, 10.0, scale)
+    g = torch.randn_like(out)
+    out.backward(g)
+    qd, kd, vd = (t.detach().double().cpu().requires_grad_(True) for t in (q, k, v))
+    r0 = 0
+    refs = []
+    for n, d in zip(counts, des):
+        o, a = R.dafm_ref(qd[r0:r0 + n], kd[r0:r0 + n], vd[r0:r0 + n], d.double(), 10.0, scale)
+        refs.append(o)
+        o_np, _ = oracle.dafm_attention(qd[r0:r0 + n].detach().numpy(), kd[r0:r0 + n].detach().numpy(),
+                                        vd[r0:r0 + n].detach().numpy(), d.numpy(), 10.0, scale)
+        close(out[r0:r0 + n], torch.from_numpy(o_np))
+        r0 += n
+    ref = torch.cat(refs)
+    ref.backward(g.double().cpu())
+    close(out, ref)
+    close(q.grad, qd.grad); close(k.grad, kd.grad); close(v.grad, vd.grad)
+
+
+@pytest.mark.parametrize("n,heads,ch,train", [(6, 2, 64, False), (32, 8, 512, False), (9, 4, 128, True)])
+def test_gatv2_fwd_bwd(oracle, n, heads, ch, train):
+    from multimodal_gar_amd.graph_ops import GATv2Conv
+    torch.manual_seed(2)
+    conv = GATv2Conv(ch, ch, heads, dropout=0.5, concat=False).cuda()
+    conv.train(train)
+    x = torch.randn(n, ch).cuda().requires_grad_(True)
+    comb = torch.combinations(torch.arange(n), r=2)
+    edge_index = torch.cat((comb, torch.flip(comb, [1])), 0).T.cuda()        # model/gat_model.py:1085-1092
+    torch.manual_seed(7)
+    out, (rowptr, col, alpha) = conv(x, edge_index, return_attention_weights=True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    edge_scale = None
+    if train:  # replay the same dropout mask in the reference
+        torch.manual_seed(7)
+        keep = 0.5
+        mask = torch.bernoulli(torch.full((col.numel(), heads), keep, device="cuda")) / keep
+        rp = rowptr.cpu().tolist(); cl = col.cpu().tolist()
+        edge_scale = {}
+        for i in range(n):
+            for e in range(rp[i], rp[i + 1]):
+                edge_scale[(cl[e], i)] = mask[e].double().cpu()
+    ref_conv = GATv2Conv(ch, ch, heads, dropout=0.5, concat=False).double()
+    ref_conv.load_state_dict({k_: v_.double().cpu() for k_, v_ in conv.state_dict().items()})
+    xd = x.detach().double().cpu().requires_grad_(True)
+    ref = R.gatv2_ref(xd, edge_index.cpu(), ref_conv.lin_l, ref_conv.lin_r, ref_conv.att, ref_conv.bias, heads, ch,
+                      edge_scale=edge_scale)
+    ref.backward(g.double().cpu())
+    close(out, ref)
+    close(x.grad, xd.grad)
+    for (na, pa), (nb, pb) in zip(conv.named_parameters(), ref_conv.named_parameters()):
+        close(pa.grad, pb.grad, rtol=2e-4)
+    if not train:
+        sd = conv.state_dict()
+        onp = oracle.gatv2(x.detach().cpu().numpy(), edge_index.cpu().numpy(), sd["lin_l.weight"].cpu().numpy(),
+                           sd["lin_l.bias"].cpu().numpy(), sd["lin_r.weight"].cpu().numpy(), sd["lin_r.bias"].cpu().numpy(),
+                           sd["att"].cpu().numpy(), sd["bias"].cpu().numpy(), heads, ch)
+        close(out, torch.from_numpy(onp))
+
+
+def test_giou_and_pairwise_against_numpy(oracle):
+    from multimodal_gar_amd.vision_ops import generalized_box_iou
+    from multimodal_gar_amd.metric_ops import pairwise_cosine_similarity, pairwise_euclidean_distance
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(0, 500, (20, 2)); wh = rng.uniform(5, 200, (20, 2))
+    boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    close(generalized_box_iou(torch.from_numpy(boxes).cuda(), torch.from_numpy(boxes).cuda()),
+          torch.from_numpy(oracle.generalized_box_iou(boxes, boxes)))
+    x = rng.standard_normal((20, 3)).astype(np.float32)
+    close(pairwise_euclidean_distance(torch.from_numpy(x).cuda(), zero_diagonal=True),
+          torch.from_numpy(oracle.pairwise_euclidean_distance(x)))
+    f = rng.standard_normal((20, 512)).astype(np.float32)
+    close(pairwise_cosine_similarity(torch.from_numpy(f).cuda(), zero_diagonal=False),
+          torch.from_numpy(oracle.pairwise_cosine_similarity(f)))
