@@ -1,0 +1,242 @@
+"""RGB backbone blocks: Inception-I3D and the non-local block.
+
+Mirror of the public surface of the reference's model/backbone.py (class names, constructor
+and forward signatures, sub-module / parameter names and shapes, so that the Kinetics
+``rgb_imagenet.pt`` checkpoint the reference loads at model/gat_model.py:990-991 and the
+reference's own checkpoints load here unchanged):
+  MaxPool3dSamePadding (backbone.py:99-131), Unit3D (:134-206), InceptionModule (:210-235),
+  InceptionI3d (:238-425), NLBlockND (:558-687).
+The dense convolutions stay on PyTorch-ROCm / MIOpen: they are
+GEMM-shaped library work, not irregular-index kernels.
+
+Difference in mechanism, not in result: TensorFlow-"same" padding is symmetric whenever the
+total pad is even (every stride-1 odd-kernel layer); in that case the pad is handed to the
+convolution itself instead of materialising a padded copy of the activation with F.pad.
+"""
+from typing import Sequence, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def _same_pad_1d(size: int, kernel: int, stride: int) -> Tuple[int, int]:
+    """(front, back) padding of TF 'same' mode (backbone.py:101-105, :123-128)."""
+    total = max(kernel - stride, 0) if size % stride == 0 else max(kernel - (size % stride), 0)
+    front = total // 2
+    return front, total - front
+
+
+def _same_pads(shape_thw: Sequence[int], kernel: Sequence[int], stride: Sequence[int]):
+    return [_same_pad_1d(s, k, st) for s, k, st in zip(shape_thw, kernel, stride)]
+
+
+def _as_fpad(pads):
+    # F.pad order: last dim first -> (w_f, w_b, h_f, h_b, t_f, t_b)
+    (tf, tb), (hf, hb), (wf, wb) = pads
+    return (wf, wb, hf, hb, tf, tb)
+
+
+class MaxPool3dSamePadding(nn.MaxPool3d):
+    def compute_pad(self, dim, s):
+        return sum(_same_pad_1d(s, self.kernel_size[dim], self.stride[dim]))
+
+    def forward(self, x):
+        pads = _same_pads(x.shape[2:], self.kernel_size, self.stride)
+        return super().forward(F.pad(x, _as_fpad(pads)))  # zero pad, as the reference
+
+
+class Unit3D(nn.Module):
+    """Conv3d (no bias by default) + BatchNorm3d(eps=1e-3, momentum=0.01) + ReLU with dynamic
+    'same' padding."""
+
+    def __init__(self, in_channels, output_channels, kernel_shape=(1, 1, 1), stride=(1, 1, 1), padding=0,
+                 activation_fn=F.relu, use_batch_norm=True, use_bias=False, name='unit_3d'):
+        super().__init__()
+        self._output_channels = output_channels
+        self._kernel_shape = tuple(kernel_shape)
+        self._stride = tuple(stride)
+        self._use_batch_norm = use_batch_norm
+        self._activation_fn = activation_fn
+        self._use_bias = use_bias
+        self.name = name
+        self.padding = padding
+        self.conv3d = nn.Conv3d(in_channels, output_channels, kernel_size=self._kernel_shape, stride=self._stride,
+                                padding=0, bias=use_bias)
+        if use_batch_norm:
+            self.bn = nn.BatchNorm3d(output_channels, eps=0.001, momentum=0.01)
+
+    def compute_pad(self, dim, s):
+        return sum(_same_pad_1d(s, self._kernel_shape[dim], self._stride[dim]))
+
+    def forward(self, x):
+        pads = _same_pads(x.shape[2:], self._kernel_shape, self._stride)
+        if all(f == b for f, b in pads):
+            x = F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
+        else:
+            x = self.conv3d(F.pad(x, _as_fpad(pads)))
+        if self._use_batch_norm:
+            x = self.bn(x)
+        if self._activation_fn is not None:
+            x = self._activation_fn(x)
+        return x
+
+
+class InceptionModule(nn.Module):
+    def __init__(self, in_channels, out_channels, name):
+        super().__init__()
+        oc = out_channels
+        self.b0 = Unit3D(in_channels, oc[0], [1, 1, 1], name=name + '/Branch_0/Conv3d_0a_1x1')
+        self.b1a = Unit3D(in_channels, oc[1], [1, 1, 1], name=name + '/Branch_1/Conv3d_0a_1x1')
+        self.b1b = Unit3D(oc[1], oc[2], [3, 3, 3], name=name + '/Branch_1/Conv3d_0b_3x3')
+        self.b2a = Unit3D(in_channels, oc[3], [1, 1, 1], name=name + '/Branch_2/Conv3d_0a_1x1')
+        self.b2b = Unit3D(oc[3], oc[4], [3, 3, 3], name=name + '/Branch_2/Conv3d_0b_3x3')
+        self.b3a = MaxPool3dSamePadding(kernel_size=[3, 3, 3], stride=(1, 1, 1), padding=0)
+        self.b3b = Unit3D(in_channels, oc[5], [1, 1, 1], name=name + '/Branch_3/Conv3d_0b_1x1')
+        self.name = name
+
+    def forward(self, x):
+        return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
+
+
+# (endpoint, kind, spec).  Channel plan of Inception-v1 I3D (backbone.py:305-375).
+_I3D_PLAN = (
+    ('Conv3d_1a_7x7', 'conv', dict(cin=None, cout=64, k=[7, 7, 7], s=(2, 2, 2), pad=(3, 3, 3))),
+    ('MaxPool3d_2a_3x3', 'pool', dict(k=[1, 3, 3], s=(1, 2, 2))),
+    ('Conv3d_2b_1x1', 'conv', dict(cin=64, cout=64, k=[1, 1, 1], s=(1, 1, 1), pad=0)),
+    ('Conv3d_2c_3x3', 'conv', dict(cin=64, cout=192, k=[3, 3, 3], s=(1, 1, 1), pad=1)),
+    ('MaxPool3d_3a_3x3', 'pool', dict(k=[1, 3, 3], s=(1, 2, 2))),
+    ('Mixed_3b', 'mixed', dict(cin=192, oc=[64, 96, 128, 16, 32, 32])),
+    ('Mixed_3c', 'mixed', dict(cin=256, oc=[128, 128, 192, 32, 96, 64])),
+    ('MaxPool3d_4a_3x3', 'pool', dict(k=[3, 3, 3], s=(2, 2, 2))),
+    ('Mixed_4b', 'mixed', dict(cin=480, oc=[192, 96, 208, 16, 48, 64])),
+    ('Mixed_4c', 'mixed', dict(cin=512, oc=[160, 112, 224, 24, 64, 64])),
+    ('Mixed_4d', 'mixed', dict(cin=512, oc=[128, 128, 256, 24, 64, 64])),
+    ('Mixed_4e', 'mixed', dict(cin=512, oc=[112, 144, 288, 32, 64, 64])),
+    ('Mixed_4f', 'mixed', dict(cin=528, oc=[256, 160, 320, 32, 128, 128])),
+    ('MaxPool3d_5a_2x2', 'pool', dict(k=[2, 2, 2], s=(2, 2, 2))),
+    ('Mixed_5b', 'mixed', dict(cin=832, oc=[256, 160, 320, 32, 128, 128])),
+    ('Mixed_5c', 'mixed', dict(cin=832, oc=[384, 192, 384, 48, 128, 128])),
+)
+
+
+class InceptionI3d(nn.Module):
+    """Inception-v1 I3D (Carreira & Zisserman 2017).  MGAR-net builds it up to 'Mixed_4f'
+    (832 channels, stride (4, 16, 16)); ``extract_features`` runs the built endpoints."""
+
+    VALID_ENDPOINTS = tuple(p[0] for p in _I3D_PLAN) + ('Logits', 'Predictions')
+
+    def __init__(self, num_classes=400, spatial_squeeze=True, final_endpoint='Logits', name='inception_i3d',
+                 in_channels=3, dropout_keep_prob=0.5):
+        if final_endpoint not in self.VALID_ENDPOINTS:
+            raise ValueError('Unknown final endpoint %s' % final_endpoint)
+        super().__init__()
+        self._num_classes = num_classes
+        self._spatial_squeeze = spatial_squeeze
+        self._final_endpoint = final_endpoint
+        self.logits = None
+        self.end_points = {}
+        for end_point, kind, sp in _I3D_PLAN:
+            if kind == 'conv':
+                layer = Unit3D(in_channels if sp['cin'] is None else sp['cin'], sp['cout'], sp['k'], sp['s'], sp['pad'],
+                               name=name + end_point)
+            elif kind == 'pool':
+                layer = MaxPool3dSamePadding(kernel_size=sp['k'], stride=sp['s'], padding=0)
+            else:
+                layer = InceptionModule(sp['cin'], sp['oc'], name + end_point)
+            self.end_points[end_point] = layer
+            if self._final_endpoint == end_point:
+                return  # like the reference: the caller must call build() (gat_model.py:988)
+        self.avg_pool = nn.AvgPool3d(kernel_size=[2, 7, 7], stride=(1, 1, 1))
+        self.dropout = nn.Dropout(dropout_keep_prob)
+        self.replace_logits(num_classes)
+        self.build()
+
+    def replace_logits(self, num_classes):
+        self._num_classes = num_classes
+        self.logits = Unit3D(1024, num_classes, [1, 1, 1], padding=0, activation_fn=None, use_batch_norm=False,
+                             use_bias=True, name='logits')
+
+    def build(self):
+        for k, layer in self.end_points.items():
+            self.add_module(k, layer)
+
+    def extract_features(self, x):
+        for end_point in self.VALID_ENDPOINTS:
+            if end_point in self.end_points:
+                x = self._modules[end_point](x)
+        return x
+
+    def forward(self, x):
+        x = self.logits(self.dropout(self.avg_pool(self.extract_features(x))))
+        return x.squeeze(3).squeeze(3) if self._spatial_squeeze else x
+
+
+class NLBlockND(nn.Module):
+    """Non-local block (Wang et al. 2018) without sub-sampling; modes gaussian / embedded / dot /
+    concatenate.  MGAR-net uses mode='dot': f = theta^T phi / N, no softmax (backbone.py:673-675).
+    With bn_layer the BN after W_z starts at gamma = beta = 0, i.e. the block is the identity at
+    initialisation (:612-614)."""
+
+    def __init__(self, in_channels, inter_channels=None, mode='embedded', dimension=3, bn_layer=True):
+        super().__init__()
+        assert dimension in [1, 2, 3]
+        if mode not in ['gaussian', 'embedded', 'dot', 'concatenate']:
+            raise ValueError('`mode` must be one of `gaussian`, `embedded`, `dot` or `concatenate`')
+        self.mode, self.dimension, self.in_channels = mode, dimension, in_channels
+        self.inter_channels = inter_channels if inter_channels is not None else max(in_channels // 2, 1)
+        conv_nd = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}[dimension]
+        bn = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}[dimension]
+        self.g = conv_nd(self.in_channels, self.inter_channels, kernel_size=1)
+        if bn_layer:
+            self.W_z = nn.Sequential(conv_nd(self.inter_channels, self.in_channels, kernel_size=1), bn(self.in_channels))
+            nn.init.constant_(self.W_z[1].weight, 0)
+            nn.init.constant_(self.W_z[1].bias, 0)
+        else:
+            self.W_z = conv_nd(self.inter_channels, self.in_channels, kernel_size=1)
+            nn.init.constant_(self.W_z.weight, 0)
+            nn.init.constant_(self.W_z.bias, 0)
+        if mode in ('embedded', 'dot', 'concatenate'):
+            self.theta = conv_nd(self.in_channels, self.inter_channels, kernel_size=1)
+            self.phi = conv_nd(self.in_channels, self.inter_channels, kernel_size=1)
+        if mode == 'concatenate':
+            self.W_f = nn.Sequential(nn.Conv2d(self.inter_channels * 2, 1, kernel_size=1), nn.ReLU())
+
+    def forward(self, x):
+        """x: (N, C, T, H, W) / (N, C, H, W) / (N, C, T) for dimension 3 / 2 / 1."""
+        n = x.size(0)
+        g_x = self.g(x).view(n, self.inter_channels, -1).permute(0, 2, 1)          # (N, P, Ci)
+        if self.mode == 'gaussian':
+            theta_x = x.view(n, self.in_channels, -1).permute(0, 2, 1)
+            f = torch.matmul(theta_x, x.view(n, self.in_channels, -1))
+        elif self.mode in ('embedded', 'dot'):
+            theta_x = self.theta(x).view(n, self.inter_channels, -1).permute(0, 2, 1)
+            f = torch.matmul(theta_x, self.phi(x).view(n, self.inter_channels, -1))  # (N, P, P)
+        else:
+            theta_x = self.theta(x).view(n, self.inter_channels, -1, 1)
+            phi_x = self.phi(x).view(n, self.inter_channels, 1, -1)
+            h, w = theta_x.size(2), phi_x.size(3)
+            f = self.W_f(torch.cat([theta_x.repeat(1, 1, 1, w), phi_x.repeat(1, 1, h, 1)], dim=1))
+            f = f.view(f.size(0), f.size(2), f.size(3))
+        if self.mode in ('gaussian', 'embedded'):
+            f_div_c = F.softmax(f, dim=-1)
+        else:
+            f_div_c = f / f.size(-1)
+        y = torch.matmul(f_div_c, g_x).permute(0, 2, 1).contiguous()
+        y = y.view(n, self.inter_channels, *x.size()[2:])
+        return self.W_z(y) + x
+
+
+def _needs_torchvision(name):
+    class _Missing(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+            raise ImportError('%s wraps torchvision.models (reference backbone.py:7-96); torchvision is not '
+                              'available and these ImageNet backbones are not on the MGAR-net hot path' % name)
+    _Missing.__name__ = name
+    return _Missing
+
+
+MyInception_v3 = _needs_torchvision('MyInception_v3')
+MyVGG16 = _needs_torchvision('MyVGG16')
+MyVGG19 = _needs_torchvision('MyVGG19')

@@ -1,0 +1,46 @@
+"""The three pcdet helpers that feed voxel RoI pooling (reference pcdet/utils/common_utils.py):
+rotate_points_along_z (:35-57), get_voxel_centers (:66-82), generate_voxel2pinds (:235-252).
+torch only; the rest of the reference file (loggers, dist init, SharedArray) is outside the
+hot path."""
+import numpy as np
+import torch
+
+
+def check_numpy_to_torch(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(x).float(), True
+    return x, False
+
+
+def rotate_points_along_z(points, angle):
+    """points (B, N, 3 + C), angle (B) about z, x -> y positive."""
+    points, is_numpy = check_numpy_to_torch(points)
+    angle, _ = check_numpy_to_torch(angle)
+    cosa, sina = torch.cos(angle), torch.sin(angle)
+    zeros, ones = angle.new_zeros(points.shape[0]), angle.new_ones(points.shape[0])
+    rot = torch.stack((cosa, sina, zeros, -sina, cosa, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3).float()
+    out = torch.cat((torch.matmul(points[:, :, 0:3], rot), points[:, :, 3:]), dim=-1)
+    return out.numpy() if is_numpy else out
+
+
+def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):
+    """voxel_coords (N, 3) [z, y, x] -> centres (N, 3) xyz."""
+    assert voxel_coords.shape[1] == 3
+    centers = voxel_coords[:, [2, 1, 0]].float()
+    vs = torch.tensor(voxel_size, device=centers.device).float() * downsample_times
+    lo = torch.tensor(point_cloud_range[0:3], device=centers.device).float()
+    return (centers + 0.5) * vs + lo
+
+
+def scatter_point_inds(indices, point_inds, shape):
+    ret = -1 * torch.ones(*shape, dtype=point_inds.dtype, device=point_inds.device)
+    flat = indices.view(-1, indices.shape[-1])
+    ret[tuple(flat[:, i] for i in range(flat.shape[1]))] = point_inds
+    return ret
+
+
+def generate_voxel2pinds(sparse_tensor):
+    """Dense (B, Z, Y, X) int32 table: row id of the voxel in each occupied cell, -1 elsewhere."""
+    indices = sparse_tensor.indices.long()
+    rows = torch.arange(indices.shape[0], device=indices.device, dtype=torch.int32)
+    return scatter_point_inds(indices, rows, [sparse_tensor.batch_size] + list(sparse_tensor.spatial_shape))

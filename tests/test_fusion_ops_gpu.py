@@ -116,8 +116,22 @@ def test_gatv2_fwd_bwd(oracle, n, heads, ch, train):
     ref.backward(g.double().cpu())
     close(out, ref)
     close(x.grad, xd.grad)
-    for (na, pa), (nb, pb) in zip(conv.named_parameters(), ref_conv.named_parameters()):
-        close(pa.grad, pb.grad, rtol=2e-4)
+    # Parameter gradients are sums over all edges with heavy cancellation (sum_j de_ij = 0), so
+    # the achievable fp32 accuracy is set by the summation order.  Bound the kernel's error by
+    # what a plain fp32 torch evaluation of the same formula achieves against float64.
+    conv32 = GATv2Conv(ch, ch, heads, dropout=0.5, concat=False).cuda()
+    conv32.load_state_dict(conv.state_dict())
+    x32 = x.detach().clone().requires_grad_(True)
+    es32 = None if edge_scale is None else {k_: v_.float().cuda() for k_, v_ in edge_scale.items()}
+    ref32 = R.gatv2_ref(x32, edge_index.cpu(), conv32.lin_l, conv32.lin_r, conv32.att, conv32.bias, heads, ch,
+                        edge_scale=es32)
+    ref32.backward(g)
+    for (na, pa), (nb, pb), (nc, pc) in zip(conv.named_parameters(), ref_conv.named_parameters(),
+                                            conv32.named_parameters()):
+        scale = pb.grad.abs().max().item() + 1e-12
+        err = (pa.grad.double().cpu() - pb.grad).abs().max().item()
+        err32 = (pc.grad.double().cpu() - pb.grad).abs().max().item()
+        assert err <= max(1e-5 + RTOL * scale, 3.0 * err32), "%s: err %g, torch-fp32 err %g, scale %g" % (na, err, err32, scale)
     if not train:
         sd = conv.state_dict()
         onp = oracle.gatv2(x.detach().cpu().numpy(), edge_index.cpu().numpy(), sd["lin_l.weight"].cpu().numpy(),

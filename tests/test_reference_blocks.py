@@ -1,0 +1,135 @@
+"""Parity against outputs of the REFERENCE's own torch classes (tests/golden/
+reference_torch_blocks.npz, produced by tests/golden/make_reference_golden.py by importing
+/root/reference/model in the build container).  Weights are re-created on both sides with
+tests/golden/param_fill.py.  Tolerance: 1e-4 relative (BASELINE.json north_star)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from param_fill import fill_deterministic  # noqa: E402
+
+G = np.load(os.path.join(HERE, "golden", "reference_torch_blocks.npz"))
+RTOL = 1e-4
+
+
+def close(a, b, rtol=RTOL, atol=1e-6):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape
+    scale = np.abs(b).max() + 1e-12
+    err = np.abs(a - b).max()
+    assert err <= atol + rtol * scale, "max err %g vs scale %g" % (err, scale)
+
+
+# ------------------------------------------------------------------ CPU: pure-torch blocks
+@pytest.mark.parametrize("tag,cin,cint,dim", [("nl2d", 32, 4, 2), ("nl3d", 24, 3, 3)])
+def test_nlblock_matches_reference(tag, cin, cint, dim):
+    from multimodal_gar_amd.model.backbone import NLBlockND
+    m = fill_deterministic(NLBlockND(cin, cint, mode='dot', dimension=dim), seed=1).eval()
+    x = torch.from_numpy(G[tag + "_x"])
+    close(m(x), G[tag + "_y"])
+    m.train()
+    close(m(x), G[tag + "_y_train"])
+
+
+def test_unit3d_same_padding_matches_reference():
+    from multimodal_gar_amd.model.backbone import Unit3D
+    u = fill_deterministic(Unit3D(3, 8, kernel_shape=[7, 7, 7], stride=(2, 2, 2)), seed=3).eval()
+    with torch.no_grad():
+        close(u(torch.from_numpy(G["unit3d_x"])), G["unit3d_y"])
+
+
+def test_i3d_mixed4f_matches_reference():
+    from multimodal_gar_amd.model.backbone import InceptionI3d
+    m = InceptionI3d(final_endpoint='Mixed_4f'); m.build()
+    assert sum(p.numel() for p in m.parameters()) == 7528256
+    fill_deterministic(m, seed=2).eval()
+    with torch.no_grad():
+        y = m.extract_features(torch.from_numpy(G["i3d_x"]))
+    assert y.shape == (1, 832, 4, 2, 3)
+    close(y, G["i3d_y"])
+
+
+def test_state_dict_keys_match_reference_names():
+    """Checkpoint compatibility: spot-check the parameter names the reference's
+    checkpoints carry."""
+    from multimodal_gar_amd.model.backbone import InceptionI3d
+    m = InceptionI3d(final_endpoint='Mixed_4f'); m.build()
+    keys = set(m.state_dict())
+    for k in ("Conv3d_1a_7x7.conv3d.weight", "Mixed_4f.b0.conv3d.weight", "Mixed_3b.b1b.bn.running_var",
+              "Mixed_4b.b3b.bn.weight"):
+        assert k in keys
+
+
+# ------------------------------------------------------------------ GPU: blocks on HIP kernels
+def _gar_cfg():
+    from multimodal_gar_amd.pcdet.config import EasyDict
+    return EasyDict(MODALITY="Multi", FUSION="Attention_mat", SIGMA=10, FEAT_NORM=True, EUCLIDEAN=True,
+                    ind_action_concat=True, sg_feat_org=False, FEATURE_DIM=1024, HIDDEN_DIM=512, sim="cosine")
+
+
+@pytest.mark.gpu
+def test_dafm_layer_matches_reference():
+    from multimodal_gar_amd.model.gat_model import FusionAttention_mat
+    fa = fill_deterministic(FusionAttention_mat(input_dim=64, out_dim=64, sigma=10), seed=4).cuda().eval()
+    R, L, De = (torch.from_numpy(G[k]).cuda() for k in ("dafm_R", "dafm_L", "dafm_De"))
+    with torch.no_grad():
+        Rp, Lp = fa(R, L, torch.zeros_like(De), De)
+    close(Rp, G["dafm_Rp"]); close(Lp, G["dafm_Lp"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["per_scene", "batched"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_gar_fusion_net3_matches_reference(route, mode):
+    from multimodal_gar_amd.model.gat_model import GAR_Fusion_Net3
+    cfg = _gar_cfg()
+    if route == "per_scene":
+        cfg.DISABLE_BATCHED = True
+    net = fill_deterministic(GAR_Fusion_Net3(cfg), seed=5).cuda()
+    assert sum(p.numel() for p in net.parameters()) == 11063872
+    rgb, lid, bb, b3 = (torch.from_numpy(G[k]).cuda() for k in ("gar_rgb", "gar_lidar", "gar_bboxes", "gar_bboxes3d"))
+    pid = torch.from_numpy(G["gar_pid"]).cuda()
+    if mode == "eval":
+        net.eval()
+    else:
+        net.train()
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+    with torch.no_grad():
+        res = net(rgb, lid, bb, b3, None, pid)
+    assert len(res) == 16
+    for i, r in enumerate(res):
+        close(r, G["gar_%s_%02d" % (mode, i)], rtol=2e-4)
+    if mode == "train":
+        close(net.bn_rgb.running_mean, G["gar_train_bn_rgb_mean"])
+        close(net.bn_rgb.running_var, G["gar_train_bn_rgb_var"])
+
+
+@pytest.mark.gpu
+def test_gar_fusion_net3_routes_agree_in_gradients():
+    """The batched route must be the same function as the reference-shaped per-scene loop,
+    including its gradients."""
+    from multimodal_gar_amd.model.gat_model import GAR_Fusion_Net3
+    rgb, lid, bb, b3 = (torch.from_numpy(G[k]).cuda() for k in ("gar_rgb", "gar_lidar", "gar_bboxes", "gar_bboxes3d"))
+    pid = torch.from_numpy(G["gar_pid"]).cuda()
+    grads = []
+    for disable in (True, False):
+        cfg = _gar_cfg(); cfg.DISABLE_BATCHED = disable
+        net = fill_deterministic(GAR_Fusion_Net3(cfg), seed=5).cuda().train()
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        r = rgb.clone().requires_grad_(True); l = lid.clone().requires_grad_(True)
+        res = net(r, l, bb, b3, None, pid)
+        loss = sum((o * o).sum() for o in res)
+        loss.backward()
+        grads.append((r.grad, l.grad, net.AttFusModule1.WQ_r.grad, net.D_embed[0].weight.grad, net.card_net[0].weight.grad))
+    for a, b in zip(*grads):
+        close(a, b.cpu().numpy(), rtol=5e-4, atol=1e-6)
