@@ -1,0 +1,228 @@
+"""The benchmark / smoke workload: one MGAR-net training step over a batch of synthetic clips.
+
+The reference has no benchmark; BASELINE.json defines the shape (config c3: 8 clips x 15 frames x
+32 actors x 16 384 points, fp32, forward + backward).  What one "clip" is here (frozen builder's
+choice, DESIGN.md section "workload"):
+
+  RGB   : the clip's T frames (B, T, 3, H, W) go through I3D once per clip, batch 1, exactly as the
+          reference runs it (BATCH_SIZE 1, mil3.yaml:161); centre temporal slice -> RoIAlign of the
+          clip's A actor boxes -> non-local block -> Linear -> GATv2 over the actor graph:
+          R tokens (A, 512) per clip.
+  LiDAR : every one of the clip's T frames is an independent scene of P points with its own A
+          actor boxes; all B*T frames form the batch of the PointNet++ stack (SA x 4 + FP x 4:
+          FPS, ball query, grouping, three-NN interpolation) and of the per-actor RoI-grid lift
+          (6^3 grid points per actor, 3 radii) -> (B*T*A, 216, 96) -> non-local block 3D ->
+          Linear(20736, 512): L tokens (A, 512) per frame.
+  fuse  : each frame is one scene for GAR_Fusion_Net3 (DAFM x 2, similarity, adjacency, group
+          pooling, 14 heads + cardinality) with R of its clip and L of the frame: B*T scenes.
+  loss  : a synthetic scalar over all 16 outputs (the reference's JRDB losses need labels and are
+          out of scope); backward through everything trainable (I3D is frozen,
+          as in the reference) and one Adam step.
+
+Data parallelism: the clip batch is sharded across ranks (one process per GPU); gradients are
+all-reduced by DistributedDataParallel over RCCL.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import synthetic as S
+from .pcdet.config import EasyDict
+
+PC_RANGE = [-20.0, -20.0, -2.0, 20.0, 20.0, 2.0]
+
+
+def lidar_model_cfg(n_points, route="pointnet2"):
+    if route == "pointnet2":
+        p = n_points
+        return EasyDict(
+            NAME="PointNet2RoI",
+            BACKBONE_3D=dict(
+                NAME="PointNet2MSG",
+                # OpenPCDet's stock PointNet2MSG plan, with the level sizes tied to the cloud size
+                SA_CONFIG=dict(NPOINTS=[p // 4, p // 16, p // 64, p // 256],
+                               RADIUS=[[0.1, 0.5], [0.5, 1.0], [1.0, 2.0], [2.0, 4.0]],
+                               NSAMPLE=[[16, 32], [16, 32], [16, 32], [16, 32]],
+                               MLPS=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]],
+                                     [[128, 196, 256], [128, 196, 256]], [[256, 256, 512], [256, 384, 512]]]),
+                FP_MLPS=[[128, 128], [256, 256], [512, 512], [512, 512]]),
+            ROI_HEAD=dict(NAME="PointGridRoIHead",
+                          # pooling geometry of mil3.yaml:105-134
+                          ROI_GRID_POOL=dict(GRID_SIZE=6, MLPS=[[32, 32], [32, 32], [32, 32]],
+                                             POOL_RADIUS=[0.4, 0.8, 1.6], NSAMPLE=[16, 16, 16], POOL_METHOD="max_pool")))
+    if route == "voxel":
+        layer = lambda r: dict(MLPS=[[32, 32]], QUERY_RANGES=[[4, 4, 4]], POOL_RADIUS=[r], NSAMPLE=[16],  # noqa: E731
+                               POOL_METHOD="max_pool")
+        return EasyDict(
+            NAME="VoxelRCNN", VFE=dict(NAME="MeanVFE"), BACKBONE_3D=dict(NAME="VoxelBackBone8x"),
+            ROI_HEAD=dict(NAME="VoxelRCNNHead", CLASS_AGNOSTIC=True, SHARED_FC=[512, 512], DP_RATIO=0.3,
+                          ROI_GRID_POOL=dict(FEATURES_SOURCE=["x_conv2", "x_conv3", "x_conv4"], PRE_MLP=True, GRID_SIZE=6,
+                                             POOL_LAYERS=dict(x_conv2=layer(0.4), x_conv3=layer(0.8), x_conv4=layer(1.6)))))
+    raise ValueError(route)
+
+
+def model_cfg(n_actors, n_points, gat=True, route="pointnet2"):
+    """The shipped configuration (Multimodal_cfg/mil3.yaml) with the synthetic sizes plugged in.
+    GAT_module is False in the shipped YAML (:86); the north-star includes the GAT path, so the
+    benchmark flips it on (SURVEY.md "facts")."""
+    return EasyDict(
+        DATALOADER=dict(train=dict(augmentation=dict(num_boxes=n_actors + 1, image_size=[720, 1280], crop_size=5))),
+        RGB_BACKBONE=dict(I3D_FREEZE=True, EMBEDDING_DIM=512, INTER_PERSON=False, GAT_module=bool(gat), two_stage_att=False),
+        LiDAR_BACKBONE=dict(CLASS_NAMES=["Pedestrian"], MODEL=lidar_model_cfg(n_points, route),
+                            SELF_ATT1=dict(USE=True, DIM=3, INTER_PERSON=False), two_stage_att=False),
+        GAR_MODEL=dict(MODALITY="Multi", FUSION="Attention_mat", SIGMA=10, FEAT_NORM=True, EUCLIDEAN=True,
+                       ind_action_concat=True, sg_feat_org=False, FEATURE_DIM=1024, HIDDEN_DIM=512, sim="cosine"))
+
+
+class SyntheticDataset:
+    """The attributes pcdet's detector template reads from a dataset (detector3d_template.py:36-44)."""
+
+    def __init__(self, voxel_size=(0.25, 0.25, 0.5)):
+        self.class_names = ["Pedestrian"]
+        self.point_feature_encoder = EasyDict(num_point_features=4)
+        self.point_cloud_range = np.array(PC_RANGE, np.float32)
+        self.voxel_size = list(voxel_size)
+        self.grid_size = np.round((self.point_cloud_range[3:] - self.point_cloud_range[:3]) / np.array(voxel_size)).astype(np.int64)
+        self.depth_downsample_factor = None
+
+
+def make_batch(seed, n_clips, n_frames, n_actors, n_points, height, width, device):
+    """Synthetic batch on `device`: dict of tensors (see module docstring for the meaning)."""
+    sc = S.scene_batch(seed, n_clips * n_frames, n_actors, n_points, num_boxes=n_actors + 1, height=height, width=width)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    rng = np.random.default_rng(seed + 1)
+    boxes2d = np.zeros((n_clips, n_actors + 1, 4), np.float32)
+    for b in range(n_clips):
+        boxes2d[b, :n_actors] = S.actor_boxes2d(rng, n_actors, height, width)
+    return {
+        "images": t(S.images(seed + 2, n_clips, n_frames, height, width)),      # (B, T, 3, H, W)
+        "bboxes": t(boxes2d),                                                     # (B, A+1, 4) key-frame boxes
+        "points": t(sc["points"]),                                                # (B*T, P, 4)
+        "bboxes3d": t(sc["bboxes3d"]),                                            # (B*T, A+1, 7)
+        "person_id": t(sc["person_id"]),                                          # (B*T, A+1)
+        "n_clips": n_clips, "n_frames": n_frames, "n_actors": n_actors,
+    }
+
+
+class ClipModel(nn.Module):
+    """GAR_Fusion_ALL plus the clip/frame plumbing described in the module docstring."""
+
+    def __init__(self, n_actors, n_points, gat=True, route="pointnet2"):
+        super().__init__()
+        from .model.gat_model import GAR_Fusion_ALL
+        self.cfg = model_cfg(n_actors, n_points, gat, route)
+        self.route = route
+        self.n_actors = n_actors
+        self.dataset = SyntheticDataset()
+        self.net = GAR_Fusion_ALL(self.cfg, self.dataset)
+        self.net.GAR_model.uniform_actor_count = n_actors
+
+    # ---- RGB: one I3D pass per clip (batch 1, like the reference) ---------------------------------
+    def rgb_tokens(self, images, bboxes):
+        from .model.gat_model import fully_connected_edges
+        rb = self.net.RGB_backbone
+        a = self.n_actors
+        toks = []
+        for b in range(images.shape[0]):
+            clip = images[b:b + 1]
+            _B, _T, _C, _H, _W = clip.shape
+            clip = clip.view(_B, _C, _T, _H, _W)                 # the reference's view (gat_model.py:1836)
+            with torch.no_grad():                                # I3D is frozen (I3D_FREEZE)
+                crops = rb.crop_features(clip, [bboxes[b]])      # (A+1, 832, 5, 5)
+            tok = rb.embed(crops[:a])                            # (A, 512)
+            if rb.cfg.GAT_module:
+                tok = rb.GAT_module(tok, fully_connected_edges([a], tok.device))
+            toks.append(tok)
+        return torch.stack(toks)                                 # (B, A, 512)
+
+    # ---- LiDAR: all frames of all clips in one batch ------------------------------------------------
+    def lidar_tokens(self, points, bboxes3d):
+        f, p, _ = points.shape
+        a = self.n_actors
+        lb = self.net.LiDAR_backbone
+        if self.route == "pointnet2":
+            bidx = torch.arange(f, device=points.device, dtype=points.dtype).view(f, 1, 1).expand(f, p, 1)
+            data = {"batch_size": f, "points": torch.cat([bidx, points], -1).view(f * p, 5),
+                    "gt_boxes": bboxes3d[:, :a, :].contiguous(),
+                    "point_batch_cnt": torch.full((f,), p, dtype=torch.int32, device=points.device)}
+        else:
+            data = voxelize_batch(points, self.dataset)
+            data["gt_boxes"] = bboxes3d[:, :a, :].contiguous()
+        tok = lb(data)                                           # (1, F*A, 512)
+        return tok.view(f, a, -1)
+
+    def forward(self, batch):
+        b, t, a = batch["n_clips"], batch["n_frames"], self.n_actors
+        rgb = self.rgb_tokens(batch["images"], batch["bboxes"])                     # (B, A, 512)
+        lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])               # (B*T, A, 512)
+        rgb_s = rgb[:, None].expand(b, t, a, rgb.shape[-1]).reshape(b * t, a, -1)   # every frame-scene of a clip
+        pad = lambda x: torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2])], 1)    # noqa: E731  -> MNP = A + 1
+        bb2 = batch["bboxes"][:, None].expand(b, t, a + 1, 4).reshape(b * t, a + 1, 4)
+        return self.net.GAR_model(pad(rgb_s), pad(lidar), bb2, batch["bboxes3d"], None, batch["person_id"])
+
+
+def voxelize_batch(points, dataset, max_points=5):
+    """(F, P, 4) -> the dict MeanVFE / the trunk stand-in consume (voxels, counts, coords [b,z,y,x]).
+    Device-side restatement of the reference's host voxeliser call (data_processor.py:15-60); the
+    voxeliser itself is a 'next' item, this is only input plumbing."""
+    f, p, c = points.shape
+    dev = points.device
+    lo = torch.tensor(dataset.point_cloud_range[:3], device=dev)
+    vs = torch.tensor(dataset.voxel_size, device=dev, dtype=points.dtype)
+    gx, gy, gz = [int(v) for v in dataset.grid_size]
+    ijk = torch.floor((points[..., :3] - lo) / vs).long()
+    ok = ((ijk >= 0) & (ijk < torch.tensor([gx, gy, gz], device=dev))).all(-1)
+    bidx = torch.arange(f, device=dev).view(f, 1).expand(f, p)
+    key = ((bidx * gz + ijk[..., 2]) * gy + ijk[..., 1]) * gx + ijk[..., 0]
+    key = torch.where(ok, key, torch.full_like(key, -1)).view(-1)
+    flat = points.view(-1, c)[key >= 0]
+    key = key[key >= 0]
+    uniq, inv, counts = torch.unique(key, return_inverse=True, return_counts=True)
+    v = uniq.numel()
+    # rank of each point inside its voxel (stable), keep the first max_points
+    order = torch.argsort(inv, stable=True)
+    start = torch.cumsum(counts, 0) - counts
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel(), device=dev) - start[inv[order]]
+    keep = rank < max_points
+    voxels = torch.zeros((v, max_points, c), device=dev, dtype=points.dtype)
+    voxels[inv[keep], rank[keep]] = flat[keep]
+    zyx = torch.stack([uniq // (gx * gy * gz), (uniq // (gx * gy)) % gz, (uniq // gx) % gy, uniq % gx], 1).int()
+    return {"batch_size": f, "voxels": voxels, "voxel_num_points": counts.clamp(max=max_points).to(points.dtype),
+            "voxel_coords": zyx}
+
+
+def synthetic_loss(outputs):
+    """Scalar over all 16 outputs so that every trainable parameter receives a gradient."""
+    return sum((o.float() ** 2).mean() for o in outputs)
+
+
+class TrainStep:
+    """model + Adam + (optional) DDP; ``run(batch)`` = forward, loss, backward, optimizer step."""
+
+    def __init__(self, n_actors, n_points, device, gat=True, route="pointnet2", ddp=False, lr=1e-3, seed=2023):
+        torch.manual_seed(seed)  # the reference seeds 2023 (train_func.py:45-47)
+        self.model = ClipModel(n_actors, n_points, gat, route).to(device)
+        self.model.train()
+        self.module = self.model
+        if ddp:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            dev_ids = [device.index] if device.type == "cuda" else None
+            self.model = DDP(self.model, device_ids=dev_ids, find_unused_parameters=False, gradient_as_bucket_view=True,
+                             bucket_cap_mb=64)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(params, lr=lr)   # train_func.py:552 Adam(lr=1e-3)
+
+    def run(self, batch):
+        self.opt.zero_grad(set_to_none=True)
+        out = self.model(batch)
+        loss = synthetic_loss(out)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+
+def trainable_parameter_count(module):
+    return sum(p.numel() for p in module.parameters() if p.requires_grad)
