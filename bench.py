@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (slow first step)")
+    ap.add_argument("--phases", action="store_true", help="print a synchronised per-phase timing of one step")
     return ap.parse_args()
 
 
@@ -127,6 +129,34 @@ def cpu_baseline(args):
                                                         args.frames, t_all)}
 
 
+def log(msg):
+    print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
+def phase_timing(step, batch):
+    """One forward/backward with a device sync after each phase (diagnostic; not the timed region)."""
+    import torch
+    m = step.module
+    out = {}
+
+    def tick(name, t0):
+        torch.cuda.synchronize(); out[name] = (time.perf_counter() - t0) * 1e3; log("phase %-12s %9.1f ms" % (name, out[name]))
+    step.opt.zero_grad(set_to_none=True)
+    t0 = time.perf_counter(); rgb = m.rgb_tokens(batch["images"], batch["bboxes"]); tick("rgb_fwd", t0)
+    t0 = time.perf_counter(); lidar = m.lidar_tokens(batch["points"], batch["bboxes3d"]); tick("lidar_fwd", t0)
+    b, t, a = batch["n_clips"], batch["n_frames"], m.n_actors
+    t0 = time.perf_counter()
+    rgb_s = rgb[:, None].expand(b, t, a, rgb.shape[-1]).reshape(b * t, a, -1)
+    pad = lambda x: torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2])], 1)  # noqa: E731
+    bb2 = batch["bboxes"][:, None].expand(b, t, a + 1, 4).reshape(b * t, a + 1, 4)
+    res = m.net.GAR_model(pad(rgb_s), pad(lidar), bb2, batch["bboxes3d"], None, batch["person_id"])
+    from multimodal_gar_amd.workload import synthetic_loss
+    loss = synthetic_loss(res); tick("fusion_fwd", t0)
+    t0 = time.perf_counter(); loss.backward(); tick("backward", t0)
+    t0 = time.perf_counter(); step.opt.step(); tick("adam", t0)
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,7 +174,8 @@ def main():
     clips_local = args.clips // world
 
     from multimodal_gar_amd import workload as W
-    torch.backends.cudnn.benchmark = True   # MIOpen find mode for the I3D convolutions
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)   # MIOpen find mode for the I3D convolutions
+    log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
     step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp)
     batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
 
@@ -153,14 +184,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step.run(batch)
+    log("model + batch ready; %.1f GB allocated" % (torch.cuda.memory_allocated() / 2 ** 30))
+    if args.phases and rank == 0 and not ddp:
+        phase_timing(step, batch)
+        phase_timing(step, batch)
+    for i in range(args.warmup):
+        step.run(batch); torch.cuda.synchronize(); log("warmup step %d done" % i)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step.run(batch)
+        if rank == 0:
+            log("timed step %d issued" % i)   # host-side only: no sync inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    log("timed region: %.1f ms/step, peak mem %.1f GB" % (elapsed / args.steps * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
     if ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

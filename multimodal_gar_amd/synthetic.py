@@ -26,6 +26,7 @@ def actor_boxes3d(rng, n_actors):
 
 
 def actor_boxes2d(rng, n_actors, height, width, min_side=16):
+    min_side = min(min_side, max(min(height, width) // 8, 1))   # tiny smoke-test images
     x1 = rng.uniform(0, width - 4 * min_side, n_actors)
     y1 = rng.uniform(0, height - 4 * min_side, n_actors)
     w = rng.uniform(min_side, np.minimum(width - x1, 12 * min_side))
