@@ -19,6 +19,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..nn_utils import PointwiseSequential, conv1x1
+
 
 def _same_pad_1d(size: int, kernel: int, stride: int) -> Tuple[int, int]:
     """(front, back) padding of TF 'same' mode (backbone.py:101-105, :123-128)."""
@@ -189,7 +191,7 @@ class NLBlockND(nn.Module):
         bn = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}[dimension]
         self.g = conv_nd(self.in_channels, self.inter_channels, kernel_size=1)
         if bn_layer:
-            self.W_z = nn.Sequential(conv_nd(self.inter_channels, self.in_channels, kernel_size=1), bn(self.in_channels))
+            self.W_z = PointwiseSequential(conv_nd(self.inter_channels, self.in_channels, kernel_size=1), bn(self.in_channels))
             nn.init.constant_(self.W_z[1].weight, 0)
             nn.init.constant_(self.W_z[1].bias, 0)
         else:
@@ -205,13 +207,13 @@ class NLBlockND(nn.Module):
     def forward(self, x):
         """x: (N, C, T, H, W) / (N, C, H, W) / (N, C, T) for dimension 3 / 2 / 1."""
         n = x.size(0)
-        g_x = self.g(x).view(n, self.inter_channels, -1).permute(0, 2, 1)          # (N, P, Ci)
+        g_x = conv1x1(self.g, x).view(n, self.inter_channels, -1).permute(0, 2, 1)  # (N, P, Ci)
         if self.mode == 'gaussian':
             theta_x = x.view(n, self.in_channels, -1).permute(0, 2, 1)
             f = torch.matmul(theta_x, x.view(n, self.in_channels, -1))
         elif self.mode in ('embedded', 'dot'):
-            theta_x = self.theta(x).view(n, self.inter_channels, -1).permute(0, 2, 1)
-            f = torch.matmul(theta_x, self.phi(x).view(n, self.inter_channels, -1))  # (N, P, P)
+            theta_x = conv1x1(self.theta, x).view(n, self.inter_channels, -1).permute(0, 2, 1)
+            f = torch.matmul(theta_x, conv1x1(self.phi, x).view(n, self.inter_channels, -1))  # (N, P, P)
         else:
             theta_x = self.theta(x).view(n, self.inter_channels, -1, 1)
             phi_x = self.phi(x).view(n, self.inter_channels, 1, -1)
@@ -224,7 +226,7 @@ class NLBlockND(nn.Module):
             f_div_c = f / f.size(-1)
         y = torch.matmul(f_div_c, g_x).permute(0, 2, 1).contiguous()
         y = y.view(n, self.inter_channels, *x.size()[2:])
-        return self.W_z(y) + x
+        return (self.W_z(y) if isinstance(self.W_z, nn.Sequential) else conv1x1(self.W_z, y)) + x
 
 
 def _needs_torchvision(name):

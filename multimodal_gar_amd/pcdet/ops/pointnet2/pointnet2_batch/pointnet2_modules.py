@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import pointnet2_utils
+from .....nn_utils import PointwiseSequential
 
 
 def shared_mlp_2d(spec: List[int]) -> nn.Sequential:
@@ -18,7 +19,7 @@ def shared_mlp_2d(spec: List[int]) -> nn.Sequential:
     layers = []
     for c_in, c_out in zip(spec[:-1], spec[1:]):
         layers += [nn.Conv2d(c_in, c_out, kernel_size=1, bias=False), nn.BatchNorm2d(c_out), nn.ReLU()]
-    return nn.Sequential(*layers)
+    return PointwiseSequential(*layers)
 
 
 def pool_over_samples(x: torch.Tensor, method: str) -> torch.Tensor:

@@ -10,13 +10,14 @@ import torch
 import torch.nn as nn
 
 from . import pointnet2_utils
+from .....nn_utils import PointwiseSequential
 
 
 def _shared_mlp_2d(spec):
     layers = []
     for c_in, c_out in zip(spec[:-1], spec[1:]):
         layers += [nn.Conv2d(c_in, c_out, kernel_size=1, bias=False), nn.BatchNorm2d(c_out), nn.ReLU()]
-    return nn.Sequential(*layers)
+    return PointwiseSequential(*layers)
 
 
 def build_local_aggregation_module(input_channels, config):

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from . import voxel_query_utils
+from .....nn_utils import PointwiseSequential
 
 
 class NeighborVoxelSAModuleMSG(nn.Module):
@@ -23,11 +24,11 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         self.mlps_out = nn.ModuleList()
         for max_range, nsample, radius, spec in zip(query_ranges, nsamples, radii, mlps):
             self.groupers.append(voxel_query_utils.VoxelQueryAndGrouping(max_range, radius, nsample))
-            self.mlps_in.append(nn.Sequential(nn.Conv1d(spec[0], spec[1], kernel_size=1, bias=False),
+            self.mlps_in.append(PointwiseSequential(nn.Conv1d(spec[0], spec[1], kernel_size=1, bias=False),
                                               nn.BatchNorm1d(spec[1])))
-            self.mlps_pos.append(nn.Sequential(nn.Conv2d(3, spec[1], kernel_size=1, bias=False),
+            self.mlps_pos.append(PointwiseSequential(nn.Conv2d(3, spec[1], kernel_size=1, bias=False),
                                                nn.BatchNorm2d(spec[1])))
-            self.mlps_out.append(nn.Sequential(nn.Conv1d(spec[1], spec[2], kernel_size=1, bias=False),
+            self.mlps_out.append(PointwiseSequential(nn.Conv1d(spec[1], spec[2], kernel_size=1, bias=False),
                                                nn.BatchNorm1d(spec[2]), nn.ReLU()))
         self.relu = nn.ReLU()
         self.pool_method = pool_method
