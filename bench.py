@@ -110,7 +110,13 @@ def cpu_baseline(args):
     from multimodal_gar_amd import workload as W
     from oracle import oracle as O
     from oracle.cpu_backend import use_cpu_oracle
-    cores = args.cpu_threads or (os.cpu_count() or 1)
+    # the GPU box hands one GPU a share of the host: use the CPUs this process may run on,
+    # capped at 16 (oversubscribing the 256 logical CPUs the OS reports is 10x slower)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = args.cpu_threads or max(1, min(avail, 16))
     torch.set_num_threads(cores)
     O.build(); O.set_threads(cores)
     dev = torch.device("cpu")
@@ -143,6 +149,17 @@ def phase_timing(step, batch):
         torch.cuda.synchronize(); out[name] = (time.perf_counter() - t0) * 1e3; log("phase %-12s %9.1f ms" % (name, out[name]))
     step.opt.zero_grad(set_to_none=True)
     t0 = time.perf_counter(); rgb = m.rgb_tokens(batch["images"], batch["bboxes"]); tick("rgb_fwd", t0)
+    if m.route == "pointnet2":   # split the LiDAR forward: SA/FP trunk, RoI-grid lift, NL block + embedding
+        import torch as _t
+        pts, b3 = batch["points"], batch["bboxes3d"]
+        f, p, _ = pts.shape
+        lb = m.net.LiDAR_backbone
+        with _t.no_grad():
+            bidx = _t.arange(f, device=pts.device, dtype=pts.dtype).view(f, 1, 1).expand(f, p, 1)
+            data = {"batch_size": f, "points": _t.cat([bidx, pts], -1).view(f * p, 5), "gt_boxes": b3[:, :m.n_actors, :].contiguous(),
+                    "point_batch_cnt": _t.full((f,), p, dtype=_t.int32, device=pts.device)}
+            t0 = time.perf_counter(); data = lb.model.backbone_3d(data); tick(" sa_fp_trunk", t0)
+            t0 = time.perf_counter(); data = lb.model.roi_head(data); tick(" roi_grid_lift", t0)
     t0 = time.perf_counter(); lidar = m.lidar_tokens(batch["points"], batch["bboxes3d"]); tick("lidar_fwd", t0)
     b, t, a = batch["n_clips"], batch["n_frames"], m.n_actors
     t0 = time.perf_counter()

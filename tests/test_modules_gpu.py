@@ -1,0 +1,136 @@
+"""Module-level integration parity (SURVEY.md section 4 plan): the same host-side module is run on the GPU
+(HIP kernels) and on the CPU with the C oracle standing in for the kernels
+(oracle/cpu_backend.py), from identical parameters and inputs.  Covers rows a8, a9, a12, a14, a15,
+a16 and the whole clip model (a24) of SURVEY.md section 8."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from param_fill import fill_deterministic  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    assert a.shape == b.shape
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, "max err %g vs scale %g" % (err, scale)
+
+
+def run_both(make_module, inputs, train=True, seed=3):
+    """-> (gpu_out, gpu_grads), (cpu_out, cpu_grads): outputs and input gradients from both backends."""
+    from oracle.cpu_backend import use_cpu_oracle
+    mod = fill_deterministic(make_module(), seed=seed)
+    mod.train(train)
+    res = []
+    for dev in ("cuda", "cpu"):
+        m = copy.deepcopy(mod).to(dev)
+        ins = [t.detach().clone().to(dev).requires_grad_(t.is_floating_point() and t.dim() > 1 and rg)
+               for t, rg in inputs]
+        ctx = use_cpu_oracle() if dev == "cpu" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            out = m(*ins)
+            outs = [o for o in (out if isinstance(out, (tuple, list)) else (out,)) if torch.is_tensor(o) and o.is_floating_point()]
+            loss = sum((o * o).sum() for o in outs if o.requires_grad)
+            loss.backward()
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+        grads = [t.grad for t in ins if t.requires_grad] + [p.grad for p in m.parameters() if p.grad is not None]
+        res.append((outs, grads))
+    return res
+
+
+def scene(seed, b, n):
+    from multimodal_gar_amd import synthetic as S
+    sc = S.scene_batch(seed, b, 4, n)
+    return torch.from_numpy(np.ascontiguousarray(sc["points"][:, :, :3])), torch.from_numpy(sc["bboxes3d"])
+
+
+def test_sa_msg_and_fp_modules_batch():
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_modules as M
+    xyz, _ = scene(1, 2, 1024)
+    feats = torch.randn(2, 5, 1024)
+    (go, gg), (co, cg) = run_both(lambda: M.PointnetSAModuleMSG(npoint=128, radii=[0.8, 2.0], nsamples=[8, 16],
+                                                                mlps=[[5, 16, 32], [5, 16, 32]]),
+                                  [(xyz, False), (feats, True)])
+    for a, b in zip(go, co):
+        close(a, b)
+    for a, b in zip(gg, cg):
+        close(a, b, rtol=5e-4)
+    known = xyz[:, :100].contiguous(); kf = torch.randn(2, 12, 100); uf = torch.randn(2, 7, 1024)
+    (go, gg), (co, cg) = run_both(lambda: M.PointnetFPModule(mlp=[19, 32, 16]), [(xyz, False), (known, False), (uf, True), (kf, True)])
+    for a, b in zip(go + gg, co + cg):
+        close(a, b, rtol=5e-4)
+
+
+def test_stack_sa_and_fp_modules():
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as M
+    xyz, _ = scene(2, 2, 700)
+    xyz = xyz.reshape(-1, 3)
+    cnt = torch.tensor([700, 700], dtype=torch.int32)
+    new_xyz = torch.cat([xyz[:50], xyz[700:760] + 0.05, torch.tensor([[900., 900., 900.]])])   # last query: empty ball
+    ncnt = torch.tensor([50, 61], dtype=torch.int32)
+    feats = torch.randn(1400, 9)
+    (go, gg), (co, cg) = run_both(lambda: M.StackSAModuleMSG(radii=[0.9, 2.5], nsamples=[8, 16], mlps=[[9, 16], [9, 24]]),
+                                  [(xyz, False), (cnt, False), (new_xyz, False), (ncnt, False), (feats, True)])
+    close(go[1], co[1])
+    for a, b in zip(gg, cg):
+        close(a, b, rtol=5e-4)
+    kf = torch.randn(111, 6)
+    (go, gg), (co, cg) = run_both(lambda: M.StackPointnetFPModule(mlp=[15, 20]),
+                                  [(xyz, False), (cnt, False), (new_xyz, False), (ncnt, False), (feats, True), (kf, True)])
+    for a, b in zip(go + gg, co + cg):
+        close(a, b, rtol=5e-4)
+
+
+def test_voxel_rcnn_route_detector():
+    """MeanVFE -> trunk stand-in -> VoxelRCNNHead (voxel query + NeighborVoxelSAModuleMSG)."""
+    from multimodal_gar_amd import workload as W
+    from multimodal_gar_amd.pcdet.models import build_network
+    from oracle.cpu_backend import use_cpu_oracle
+    ds = W.SyntheticDataset()
+    pts, b3 = scene(3, 2, 4096)
+    points = torch.cat([pts, torch.rand(2, 4096, 1)], -1)
+    net = fill_deterministic(build_network(W.lidar_model_cfg(4096, "voxel"), 1, ds), seed=9).eval()
+    outs = []
+    for dev in ("cuda", "cpu"):
+        m = copy.deepcopy(net).to(dev)
+        data = W.voxelize_batch(points.to(dev), ds)
+        data["gt_boxes"] = b3[:, :4, :].contiguous().to(dev)
+        if dev == "cpu":
+            with use_cpu_oracle(), torch.no_grad():
+                outs.append(m(data)["pooled_features"])
+        else:
+            with torch.no_grad():
+                outs.append(m(data)["pooled_features"])
+    assert outs[0].shape == (8, 216, 96)
+    close(outs[0], outs[1])
+    assert outs[1].abs().sum() > 0
+
+
+def test_clip_model_forward_gpu_vs_cpu_backend():
+    from multimodal_gar_amd import workload as W
+    from oracle.cpu_backend import use_cpu_oracle
+    torch.manual_seed(0)
+    model = fill_deterministic(W.ClipModel(4, 1024), seed=11).eval()
+    batch = W.make_batch(5, 1, 2, 4, 1024, 64, 96, torch.device("cpu"))
+    with use_cpu_oracle(), torch.no_grad():
+        want = model(batch)
+    gm = copy.deepcopy(model).cuda()
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        got = gm(gb)
+    assert len(got) == 16
+    for a, b in zip(got, want):
+        close(a, b, rtol=5e-4, atol=1e-5)
