@@ -132,6 +132,35 @@ int mgar_three_interpolate_stack(int N, int C, const float *features, const int 
 int mgar_three_interpolate_grad_stack(int N, int C, const float *grad_out, const int *idx, const float *weight,
                                       float *grad_features, void *stream);
 
+/* ===================== fused query-and-group ==================== */
+
+/* The torch op chain of QueryAndGroup.forward after ball_query
+ * (pointnet2_batch/pointnet2_utils.py:241-264: transpose, group xyz, subtract centre, group
+ * features, cat) as one kernel.  xyz (b,n,3), new_xyz (b,npoints,3), features (b,c,n) or NULL
+ * with c = 0, idx (b,npoints,nsample) -> out (b, 3+c, npoints, nsample): rows 0..2 are the
+ * neighbour coordinates relative to the query, rows 3.. the grouped features.
+ * bwd: the feature rows of grad_out (b, 3+c, npoints, nsample) are accumulated into the
+ * caller-zeroed grad_features (b,c,n); xyz receives no gradient (as in the reference, where
+ * xyz never requires grad). */
+int mgar_query_group_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz,
+                               const float *new_xyz, const float *features, const int *idx, float *out,
+                               void *stream);
+int mgar_query_group_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                               const int *idx, float *grad_features, void *stream);
+
+/* Stacked layout (pointnet2_stack/pointnet2_utils.py:123-159 + the permute of
+ * pointnet2_stack/pointnet2_modules.py:95): idx (M,nsample) is the RAW output of
+ * mgar_ball_query_stack (idx[row][0] == -1 marks an empty ball, whose columns are zero-filled);
+ * out is CHANNEL-MAJOR (3+C, M*nsample), the layout the shared MLP's GEMM consumes.
+ * bwd accumulates the feature rows of grad_out (3+C, M*nsample) into caller-zeroed
+ * grad_features (N,C). */
+int mgar_query_group_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                               const float *new_xyz, const int *new_xyz_batch_cnt, const float *features,
+                               const int *idx, float *out, void *stream);
+int mgar_query_group_stack_bwd(int B, int M, int C, int nsample, const float *grad_out, const int *idx,
+                               const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_features,
+                               void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).

@@ -40,6 +40,10 @@ _PROTOS = {
     "mgar_three_nn_stack": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_stack": [_I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_stack": [_I, _I, _P, _P, _P, _P, _P],
+    "mgar_query_group_batch_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_batch_bwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_query_group_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_dafm_attn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],

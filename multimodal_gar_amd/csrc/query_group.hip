@@ -1,0 +1,265 @@
+// query_group.hip -- fused "query and group": relative xyz + grouped features written ONCE, in
+// the layout the shared MLP's GEMM consumes.
+//
+// Replaces the torch op chains of the reference's
+//   pointnet2_batch/pointnet2_utils.py:241-264  QueryAndGroup.forward  (dense batches)
+//   pointnet2_stack/pointnet2_utils.py:123-159  QueryAndGroup.forward  (stacked batches)
+// which, after ball_query, run: transpose xyz -> group xyz -> subtract centre -> (stack: zero the
+// empty balls) -> group features -> (stack: zero) -> cat -> (stack: permute for the conv).  Every
+// one of those is a full pass over the grouped tensor (1.7 GB per scale for the RoI-grid lift at
+// config c3); the concatenation alone re-reads and re-writes all of it.  Here one kernel reads the
+// neighbour indices and writes the final (3 + C)-channel tensor exactly once.
+//
+//   batch : out (B, 3+C, M, ns), same layout the reference's module returns.
+//   stack : out (3+C, M*ns) CHANNEL-MAJOR -- what `mlp(new_features.permute(1,0,2).unsqueeze(0))`
+//           (pointnet2_stack/pointnet2_modules.py:95-96) needs, so that permute copy disappears too.
+//           Feature rows are gathered with lanes along c (one contiguous 128-byte piece per
+//           neighbour) into an LDS tile and written with lanes along the columns (coalesced);
+//           the backward does the same in reverse and adds whole contiguous row pieces with
+//           float atomics (the full-rate shape on MI355X).
+// The stack kernels consume the RAW ball-query output (idx[row][0] == -1 marks an empty ball,
+// pointnet2_stack/src/ball_query_gpu.cu:65) so the host needs no mask / fix-up passes either.
+#include "common.hpp"
+
+namespace mgar {
+
+// ------------------------------------------------------------------------------------------
+// batch
+// ------------------------------------------------------------------------------------------
+constexpr int QG_CCHUNK = 8;
+
+// grid: (ceil(cols/256), 1 + ceil(c/QG_CCHUNK), b); blockIdx.y == 0 writes the 3 xyz rows
+__global__ __launch_bounds__(256) void qg_batch_fwd_kernel(int c, int n, int npoints, int nsample,
+                                                           const float *__restrict__ xyz,
+                                                           const float *__restrict__ new_xyz,
+                                                           const float *__restrict__ features,
+                                                           const int *__restrict__ idx, float *__restrict__ out) {
+    const int cols = npoints * nsample;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const int bs = blockIdx.z;
+    const int k = idx[(size_t)bs * cols + col];
+    float *dst = out + (size_t)bs * (3 + c) * cols + col;
+    if (blockIdx.y == 0) {
+        const int p = col / nsample;
+        const float *q = new_xyz + ((size_t)bs * npoints + p) * 3;
+        const float *s = xyz + ((size_t)bs * n + k) * 3;
+        dst[0] = s[0] - q[0];
+        dst[(size_t)cols] = s[1] - q[1];
+        dst[(size_t)2 * cols] = s[2] - q[2];
+        return;
+    }
+    const int c0 = (blockIdx.y - 1) * QG_CCHUNK;
+    const int c1 = min(c0 + QG_CCHUNK, c);
+    const float *src = features + ((size_t)bs * c + c0) * n + k;
+    dst += (size_t)(3 + c0) * cols;
+#pragma unroll 4
+    for (int ci = c0; ci < c1; ++ci) {
+        *dst = *src;
+        src += n;
+        dst += cols;
+    }
+}
+
+// grid: (c, b); one workgroup owns one (b, c) row of grad_features, accumulated in LDS
+__global__ __launch_bounds__(1024) void qg_batch_bwd_lds_kernel(int c, int n, int cols, const float *__restrict__ grad_out,
+                                                                const int *__restrict__ idx,
+                                                                float *__restrict__ grad_features) {
+    extern __shared__ float row[];
+    const int ci = blockIdx.x, bs = blockIdx.y;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) row[i] = 0.f;
+    __syncthreads();
+    const float *g = grad_out + ((size_t)bs * (3 + c) + 3 + ci) * cols;
+    const int *id = idx + (size_t)bs * cols;
+    for (int e = threadIdx.x; e < cols; e += blockDim.x) atomicAdd(&row[id[e]], g[e]);
+    __syncthreads();
+    float *dst = grad_features + ((size_t)bs * c + ci) * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = row[i];
+        if (v != 0.f) dst[i] += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void qg_batch_bwd_atomic_kernel(int c, int n, int cols, const float *__restrict__ grad_out,
+                                                                  const int *__restrict__ idx,
+                                                                  float *__restrict__ grad_features) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    const int ci = blockIdx.y, bs = blockIdx.z;
+    atomicAdd(grad_features + ((size_t)bs * c + ci) * n + idx[(size_t)bs * cols + col],
+              grad_out[((size_t)bs * (3 + c) + 3 + ci) * cols + col]);
+}
+
+// ------------------------------------------------------------------------------------------
+// stack
+// ------------------------------------------------------------------------------------------
+constexpr int QS_COLS = 128;   // columns (query, sample) per workgroup
+constexpr int QS_CH = 32;      // channels per LDS pass (one 128-byte piece per neighbour)
+
+struct QsTile {
+    int src_row[QS_COLS];          // global feature row of each column, -1 = empty ball
+    float tile[QS_COLS][QS_CH + 1];
+};
+
+// common prologue: resolve the tile's columns to global source rows.  The tile's queries are
+// consecutive, so one wave-uniform segment search (for the first query) serves every column that
+// is still inside that sample; only columns past its end search again.
+__device__ __forceinline__ int qs_prologue(QsTile &t, int B, int M, int nsample, const int *__restrict__ idx,
+                                           const int *__restrict__ q_cnt, const int *__restrict__ p_cnt, int &col0) {
+    __shared__ int seg_q_end, seg_p_start;
+    const long long total = (long long)M * nsample;
+    col0 = blockIdx.x * QS_COLS;
+    const int ncol = (int)min((long long)QS_COLS, total - col0);
+    if (threadIdx.x == 0) {
+        const int m0 = col0 / nsample;
+        const Segment sg = find_segment(m0, B, q_cnt, p_cnt);
+        seg_q_end = sg.a_start + q_cnt[sg.bs];
+        seg_p_start = sg.b_start;
+    }
+    __syncthreads();
+    for (int cl = threadIdx.x; cl < ncol; cl += blockDim.x) {
+        const int col = col0 + cl;
+        const int m = col / nsample;
+        const int k = idx[col];
+        const int first = idx[(size_t)m * nsample];
+        const int p_start = m < seg_q_end ? seg_p_start : find_segment(m, B, q_cnt, p_cnt).b_start;
+        t.src_row[cl] = first < 0 ? -1 : p_start + k;
+    }
+    __syncthreads();
+    return ncol;
+}
+
+__global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, int nsample, const float *__restrict__ xyz,
+                                                           const int *__restrict__ xyz_batch_cnt,
+                                                           const float *__restrict__ new_xyz,
+                                                           const int *__restrict__ new_xyz_batch_cnt,
+                                                           const float *__restrict__ features,
+                                                           const int *__restrict__ idx, float *__restrict__ out) {
+    __shared__ QsTile t;
+    int col0;
+    const int ncol = qs_prologue(t, B, M, nsample, idx, new_xyz_batch_cnt, xyz_batch_cnt, col0);
+    const size_t ms = (size_t)M * nsample;
+    // rows 0..2: neighbour xyz relative to the query, zero for an empty ball
+    for (int e = threadIdx.x; e < ncol * 3; e += 256) {
+        const int r = e / ncol, cl = e - r * ncol;
+        const int src = t.src_row[cl];
+        const int m = (col0 + cl) / nsample;
+        out[(size_t)r * ms + col0 + cl] = src < 0 ? 0.f : xyz[(size_t)src * 3 + r] - new_xyz[(size_t)m * 3 + r];
+    }
+    // rows 3..: features, QS_CH channels per pass through the LDS tile
+    for (int c0 = 0; c0 < C; c0 += QS_CH) {
+        const int nch = min(QS_CH, C - c0);
+        for (int e = threadIdx.x; e < ncol * QS_CH; e += 256) {      // lanes along c
+            const int cl = e / QS_CH, ci = e - cl * QS_CH;
+            const int src = t.src_row[cl];
+            t.tile[cl][ci] = (src >= 0 && ci < nch) ? features[(size_t)src * C + c0 + ci] : 0.f;
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < nch * QS_COLS; e += 256) {     // lanes along the columns
+            const int ci = e / QS_COLS, cl = e - ci * QS_COLS;
+            if (cl < ncol) out[(size_t)(3 + c0 + ci) * ms + col0 + cl] = t.tile[cl][ci];
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, int nsample, const float *__restrict__ grad_out,
+                                                           const int *__restrict__ idx,
+                                                           const int *__restrict__ new_xyz_batch_cnt,
+                                                           const int *__restrict__ xyz_batch_cnt,
+                                                           float *__restrict__ grad_features) {
+    __shared__ QsTile t;
+    int col0;
+    const int ncol = qs_prologue(t, B, M, nsample, idx, new_xyz_batch_cnt, xyz_batch_cnt, col0);
+    const size_t ms = (size_t)M * nsample;
+    for (int c0 = 0; c0 < C; c0 += QS_CH) {
+        const int nch = min(QS_CH, C - c0);
+        for (int e = threadIdx.x; e < nch * QS_COLS; e += 256) {     // coalesced reads of the gradient rows
+            const int ci = e / QS_COLS, cl = e - ci * QS_COLS;
+            if (cl < ncol) t.tile[cl][ci] = grad_out[(size_t)(3 + c0 + ci) * ms + col0 + cl];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < ncol * QS_CH; e += 256) {      // lanes along c: contiguous atomic pieces
+            const int cl = e / QS_CH, ci = e - cl * QS_CH;
+            const int src = t.src_row[cl];
+            if (src >= 0 && ci < nch) atomicAdd(grad_features + (size_t)src * C + c0 + ci, t.tile[cl][ci]);
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int QG_LDS_MAX_FLOATS = 36864;
+
+}  // namespace mgar
+
+using namespace mgar;
+
+extern "C" __attribute__((visibility("default"))) int mgar_query_group_batch_fwd(int b, int c, int n, int npoints,
+                                                                                int nsample, const float *xyz,
+                                                                                const float *new_xyz,
+                                                                                const float *features, const int *idx,
+                                                                                float *out, void *stream) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group_batch_fwd: negative size");
+    MGAR_REQUIRE(b <= 65535, "query_group_batch_fwd: b > 65535");
+    if ((long long)b * npoints * nsample == 0) return MGAR_OK;
+    MGAR_REQUIRE(xyz && new_xyz && idx && out && (features || c == 0), "query_group_batch_fwd: null pointer");
+    dim3 grid(ceil_div((long long)npoints * nsample, 256), 1 + ceil_div(c, QG_CCHUNK), b);
+    hipLaunchKernelGGL(qg_batch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, nsample, xyz, new_xyz,
+                       features, idx, out);
+    return check_launch("query_group_batch_fwd: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_query_group_batch_bwd(int b, int c, int n, int npoints,
+                                                                                int nsample, const float *grad_out,
+                                                                                const int *idx, float *grad_features,
+                                                                                void *stream) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group_batch_bwd: negative size");
+    MGAR_REQUIRE(b <= 65535 && c <= 65535, "query_group_batch_bwd: b or c > 65535");
+    const int cols = npoints * nsample;
+    if ((long long)b * c * cols == 0) return MGAR_OK;
+    MGAR_REQUIRE(grad_out && idx && grad_features, "query_group_batch_bwd: null pointer");
+    if (n <= QG_LDS_MAX_FLOATS) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)qg_batch_bwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      QG_LDS_MAX_FLOATS * (int)sizeof(float));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(qg_batch_bwd_lds_kernel, dim3(c, b), dim3(cols >= 4096 ? 1024 : 256), (size_t)n * sizeof(float),
+                           (hipStream_t)stream, c, n, cols, grad_out, idx, grad_features);
+    } else {
+        hipLaunchKernelGGL(qg_batch_bwd_atomic_kernel, dim3(ceil_div(cols, 256), c, b), dim3(256), 0, (hipStream_t)stream, c, n,
+                           cols, grad_out, idx, grad_features);
+    }
+    return check_launch("query_group_batch_bwd: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_query_group_stack_fwd(int B, int M, int C, int nsample,
+                                                                                const float *xyz, const int *xyz_batch_cnt,
+                                                                                const float *new_xyz,
+                                                                                const int *new_xyz_batch_cnt,
+                                                                                const float *features, const int *idx,
+                                                                                float *out, void *stream) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group_stack_fwd: negative size");
+    const long long total = (long long)M * nsample;
+    if (B == 0 || total == 0) return MGAR_OK;
+    MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && out && (features || C == 0),
+                 "query_group_stack_fwd: null pointer");
+    hipLaunchKernelGGL(qg_stack_fwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
+                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, out);
+    return check_launch("query_group_stack_fwd: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_query_group_stack_bwd(int B, int M, int C, int nsample,
+                                                                                const float *grad_out, const int *idx,
+                                                                                const int *new_xyz_batch_cnt,
+                                                                                const int *xyz_batch_cnt,
+                                                                                float *grad_features, void *stream) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group_stack_bwd: negative size");
+    const long long total = (long long)M * nsample;
+    if (B == 0 || total == 0 || C == 0) return MGAR_OK;
+    MGAR_REQUIRE(grad_out && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group_stack_bwd: null pointer");
+    hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
+                       grad_out, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features);
+    return check_launch("query_group_stack_bwd: launch failed");
+}

@@ -60,3 +60,16 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     L.call("mgar_three_interpolate_grad_batch", b, c, n, m, L.fptr(grad_out), L.iptr(idx), L.fptr(weight),
            L.fptr(grad_points), L.stream_of(grad_out))
     return 1
+
+
+# ---- fused ops that are torch op chains in the reference (no pybind counterpart) ----
+def query_group_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out):
+    L.call("mgar_query_group_batch_fwd", b, c, n, npoints, nsample, L.fptr(xyz), L.fptr(new_xyz),
+           L.fptr(features) if features is not None else None, L.iptr(idx), L.fptr(out), L.stream_of(xyz))
+    return 1
+
+
+def query_group_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_features):
+    L.call("mgar_query_group_batch_bwd", b, c, n, npoints, nsample, L.fptr(grad_out), L.iptr(idx), L.fptr(grad_features),
+           L.stream_of(grad_out))
+    return 1

@@ -180,6 +180,35 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+class _FusedQueryGroup(Function):
+    """Relative xyz (3 rows) + grouped features (C rows) written once by one kernel
+    (csrc/query_group.hip) instead of transpose / group / subtract / group / cat."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, features, idx):
+        batch, n_pts, _ = xyz.size()
+        npoint, nsample = idx.size(1), idx.size(2)
+        chans = 0 if features is None else features.size(1)
+        out = _new(xyz, (batch, 3 + chans, npoint, nsample), torch.float32)
+        pointnet2.query_group_wrapper(batch, chans, n_pts, npoint, nsample, xyz, new_xyz,
+                                      None if features is None else features.contiguous(), idx, out)
+        ctx.save_for_backward(idx)
+        ctx.dims = (chans, n_pts)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        chans, n_pts = ctx.dims
+        if chans == 0 or not ctx.needs_input_grad[2]:
+            return None, None, None, None
+        batch, _, npoint, nsample = grad_out.size()
+        grad_features = _new(grad_out, (batch, chans, n_pts), torch.float32, 0.0)
+        pointnet2.query_group_grad_wrapper(batch, chans, n_pts, npoint, nsample, grad_out.contiguous(), idx, grad_features)
+        return None, None, grad_features, None
+
+
 class QueryAndGroup(nn.Module):
     """ball_query -> group xyz (made relative to the centre) -> group features -> concat.
     Output (B, 3 + C, npoint, nsample).  Reference: pointnet2_utils.py:231-264."""
@@ -190,13 +219,11 @@ class QueryAndGroup(nn.Module):
 
     def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
         idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        rel_xyz = grouping_operation(xyz.transpose(1, 2).contiguous(), idx)  # (B, 3, npoint, nsample)
-        rel_xyz = rel_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            return rel_xyz
-        grouped = grouping_operation(features, idx)
-        return torch.cat([rel_xyz, grouped], dim=1) if self.use_xyz else grouped
+        if not self.use_xyz:
+            return grouping_operation(features, idx)
+        return _FusedQueryGroup.apply(xyz, new_xyz, features, idx)
 
 
 class GroupAll(nn.Module):

@@ -63,8 +63,8 @@ class StackSAModuleMSG(nn.Module):
         """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1]))."""
         per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            grouped, _ = grouper(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)  # (M, C, nsample)
-            x = mlp(grouped.permute(1, 0, 2).unsqueeze(0))                                  # (1, C', M, nsample)
+            grouped, _ = grouper.forward_channel_major(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
+            x = mlp(grouped.view(1, grouped.shape[0], new_xyz.shape[0], -1))                # (1, C', M, nsample)
             if self.pool_method == 'max_pool':
                 x = x.max(dim=3).values
             elif self.pool_method == 'avg_pool':

@@ -58,3 +58,17 @@ def three_interpolate_wrapper(features, idx, weight, out):
 def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
     L.call("mgar_three_interpolate_grad_stack", idx.shape[0], grad_out.shape[1], L.fptr(grad_out), L.iptr(idx),
            L.fptr(weight), L.fptr(grad_features), L.stream_of(grad_out))
+
+
+# ---- fused ops that are torch op chains in the reference (no pybind counterpart) ----
+def query_group_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx_raw, out):
+    L.call("mgar_query_group_stack_fwd", B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
+           L.iptr(new_xyz_batch_cnt), L.fptr(features) if features is not None else None, L.iptr(idx_raw), L.fptr(out),
+           L.stream_of(xyz))
+    return 1
+
+
+def query_group_grad_wrapper(B, M, C, nsample, grad_out, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_features):
+    L.call("mgar_query_group_stack_bwd", B, M, C, nsample, L.fptr(grad_out), L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt),
+           L.iptr(xyz_batch_cnt), L.fptr(grad_features), L.stream_of(grad_out))
+    return 1

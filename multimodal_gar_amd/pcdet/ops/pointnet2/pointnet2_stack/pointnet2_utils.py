@@ -84,6 +84,39 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+class _FusedQueryGroup(Function):
+    """ball query + relative xyz + grouped features, zeroed for empty balls, written once as a
+    CHANNEL-MAJOR (3 + C, M * nsample) tensor (csrc/query_group.hip).  Returns (grouped, idx_raw)
+    where idx_raw[row, 0] == -1 marks an empty ball."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features):
+        n_samples = xyz_batch_cnt.shape[0]
+        n_query = new_xyz.shape[0]
+        idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+        chans = 0 if features is None else features.shape[1]
+        out = _empty(xyz, (3 + chans, n_query * nsample), torch.float32)
+        pointnet2.query_group_wrapper(n_samples, n_query, chans, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+                                      None if features is None else features.contiguous(), idx, out)
+        ctx.save_for_backward(idx, xyz_batch_cnt, new_xyz_batch_cnt)
+        ctx.dims = (n_samples, n_query, chans, nsample, 0 if features is None else features.shape[0])
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out, grad_idx=None):
+        idx, xyz_batch_cnt, new_xyz_batch_cnt = ctx.saved_tensors
+        n_samples, n_query, chans, nsample, n_rows = ctx.dims
+        if chans == 0 or not ctx.needs_input_grad[6]:
+            return (None,) * 7
+        grad_features = torch.zeros((n_rows, chans), dtype=torch.float32, device=grad_out.device)
+        pointnet2.query_group_grad_wrapper(n_samples, n_query, chans, nsample, grad_out.contiguous(), idx,
+                                           new_xyz_batch_cnt, xyz_batch_cnt, grad_features)
+        return None, None, None, None, None, None, grad_features
+
+
 class QueryAndGroup(nn.Module):
     """Returns (new_features (M, 3 + C, nsample), idx).  Relative xyz and features of empty
     balls are zeroed.  Reference: pointnet2_utils.py:112-159."""
@@ -99,16 +132,20 @@ class QueryAndGroup(nn.Module):
             'xyz: %s, xyz_batch_cnt: %s' % (str(xyz.shape), str(new_xyz_batch_cnt))
         assert new_xyz.shape[0] == new_xyz_batch_cnt.sum(), \
             'new_xyz: %s, new_xyz_batch_cnt: %s' % (str(new_xyz.shape), str(new_xyz_batch_cnt))
-        idx, empty = ball_query(self.radius, self.nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt)
-        keep = (~empty).view(-1, 1, 1).to(xyz.dtype)
-        rel_xyz = grouping_operation(xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt)  # (M, 3, nsample)
-        rel_xyz = (rel_xyz - new_xyz.unsqueeze(-1)) * keep
+        grouped, idx_raw = self.forward_channel_major(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
+        # reference layout (M, C', nsample) as a view of the channel-major tensor; cleaned indices
+        new_features = grouped.view(grouped.shape[0], new_xyz.shape[0], self.nsample).permute(1, 0, 2)
+        idx = idx_raw.masked_fill((idx_raw[:, :1] == -1), 0)
+        return new_features, idx
+
+    def forward_channel_major(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None):
+        """-> (grouped (3 + C | C, M * nsample) channel-major, idx_raw (M, nsample) with the kernel's
+        -1 marker in column 0 of empty balls).  This is the layout the shared MLP consumes."""
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
-            return rel_xyz, idx
-        grouped = grouping_operation(features, xyz_batch_cnt, idx, new_xyz_batch_cnt) * keep
-        new_features = torch.cat([rel_xyz, grouped], dim=1) if self.use_xyz else grouped
-        return new_features, idx
+        grouped, idx_raw = _FusedQueryGroup.apply(self.radius, self.nsample, xyz, xyz_batch_cnt.int(), new_xyz,
+                                                  new_xyz_batch_cnt.int(), features)
+        return (grouped if self.use_xyz else grouped[3:]), idx_raw
 
 
 class FarthestPointSampling(Function):

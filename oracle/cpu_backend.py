@@ -64,6 +64,25 @@ class _Batch:
         O.lib().orc_three_interpolate_grad_batch(b, c, n, m, _p(grad_out), _p(idx), _p(weight), _p(grad_points)); return 1
 
 
+def _batch_query_group(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out):
+    xyz_t = xyz.transpose(1, 2).contiguous()
+    g = torch.empty((b, 3, npoints, nsample)); _Batch.group_points_wrapper(b, 3, n, npoints, nsample, xyz_t, idx, g)
+    out[:, :3] = g - new_xyz.transpose(1, 2).unsqueeze(-1)
+    if c:
+        gf = torch.empty((b, c, npoints, nsample)); _Batch.group_points_wrapper(b, c, n, npoints, nsample, features, idx, gf)
+        out[:, 3:] = gf
+    return 1
+
+
+def _batch_query_group_grad(b, c, n, npoints, nsample, grad_out, idx, grad_features):
+    _Batch.group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out[:, 3:].contiguous(), idx, grad_features)
+    return 1
+
+
+_Batch.query_group_wrapper = staticmethod(_batch_query_group)
+_Batch.query_group_grad_wrapper = staticmethod(_batch_query_group_grad)
+
+
 class _Stack:
     @staticmethod
     def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
@@ -106,6 +125,32 @@ class _Stack:
     def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
         O.lib().orc_three_interpolate_grad_stack(idx.shape[0], grad_out.shape[1], _p(grad_out), _p(idx), _p(weight),
                                                  _p(grad_features))
+
+
+def _stack_query_group(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx_raw, out):
+    empty = idx_raw[:, 0] == -1
+    idx = idx_raw.masked_fill(empty[:, None], 0).contiguous()
+    keep = (~empty).view(-1, 1, 1).float()
+    g = torch.empty((M, 3, nsample)); _Stack.group_points_wrapper(B, M, 3, nsample, xyz, xyz_batch_cnt, idx, new_xyz_batch_cnt, g)
+    out[:3] = ((g - new_xyz.unsqueeze(-1)) * keep).permute(1, 0, 2).reshape(3, -1)
+    if C:
+        gf = torch.empty((M, C, nsample))
+        _Stack.group_points_wrapper(B, M, C, nsample, features, xyz_batch_cnt, idx, new_xyz_batch_cnt, gf)
+        out[3:] = (gf * keep).permute(1, 0, 2).reshape(C, -1)
+    return 1
+
+
+def _stack_query_group_grad(B, M, C, nsample, grad_out, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_features):
+    empty = idx_raw[:, 0] == -1
+    idx = idx_raw.masked_fill(empty[:, None], 0).contiguous()
+    g = grad_out[3:].view(C, M, nsample).permute(1, 0, 2) * (~empty).view(-1, 1, 1).float()
+    _Stack.group_points_grad_wrapper(B, M, C, grad_features.shape[0], nsample, g.contiguous(), idx, new_xyz_batch_cnt,
+                                     xyz_batch_cnt, grad_features)
+    return 1
+
+
+_Stack.query_group_wrapper = staticmethod(_stack_query_group)
+_Stack.query_group_grad_wrapper = staticmethod(_stack_query_group_grad)
 
 
 # ------------------------- fused ops: plain fp32 torch on CPU (autograd by torch) -------------------------

@@ -298,3 +298,53 @@ def test_full_size_properties_batch_of_frames(ops):
     first = idx[..., :1]
     asc = (idx[..., 1:] > idx[..., :-1]) | (idx[..., 1:] == first)
     assert asc.all()
+
+
+# --------------------------------------------------------------------- fused query-and-group (a8)
+def test_fused_query_group_batch_equals_op_chain(ops):
+    """The fused kernel must reproduce the reference's chain ball_query -> group xyz -> subtract
+    centre -> group features -> cat exactly (pure copies and one subtraction), values and grads."""
+    pb = ops[0]
+    rng = np.random.default_rng(12)
+    xyz = dev(scene_xyz(31, 3, 1500))
+    new_xyz = xyz[:, :200].contiguous() + 0.01
+    feats = dev(rng.standard_normal((3, 11, 1500)).astype(np.float32)).requires_grad_(True)
+    qg = pb.QueryAndGroup(0.9, 16, use_xyz=True)
+    out = qg(xyz, new_xyz, feats)
+    g = torch.randn_like(out)
+    out.backward(g)
+    got_grad = feats.grad.clone(); feats.grad = None
+    idx = pb.ball_query(0.9, 16, xyz, new_xyz)
+    rel = pb.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+    want = torch.cat([rel, pb.grouping_operation(feats, idx)], dim=1)
+    want.backward(g)
+    assert torch.equal(out, want)
+    np.testing.assert_allclose(got_grad.cpu().numpy(), feats.grad.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    assert torch.equal(qg(xyz, new_xyz, None), rel)  # xyz-only grouping
+
+
+def test_fused_query_group_stack_equals_op_chain(ops):
+    ps = ops[1]
+    rng = np.random.default_rng(13)
+    cnt = np.array([900, 0, 1300, 70], np.int32); qcnt = np.array([150, 3, 260, 9], np.int32)
+    xyz = dev(rng.uniform(-4, 4, (int(cnt.sum()), 3)).astype(np.float32))
+    new_xyz = dev(rng.uniform(-5, 5, (int(qcnt.sum()), 3)).astype(np.float32))
+    feats = dev(rng.standard_normal((int(cnt.sum()), 45)).astype(np.float32)).requires_grad_(True)
+    c, q = dev(cnt), dev(qcnt)
+    qg = ps.QueryAndGroup(1.1, 16, use_xyz=True)
+    out, idx_fused = qg(xyz, c, new_xyz, q, feats)                       # reference layout (M, 3 + C, ns)
+    g = torch.randn(out.shape, device="cuda")
+    out.backward(g)
+    got_grad = feats.grad.clone(); feats.grad = None
+    idx, empty = ps.ball_query(1.1, 16, xyz, c, new_xyz, q)
+    keep = (~empty).view(-1, 1, 1).float()
+    rel = (ps.grouping_operation(xyz, c, idx, q) - new_xyz.unsqueeze(-1)) * keep
+    want = torch.cat([rel, ps.grouping_operation(feats, c, idx, q) * keep], dim=1)
+    want.backward(g)
+    assert empty.any() and (~empty).any()
+    assert torch.equal(idx_fused, idx)
+    assert torch.equal(out, want)
+    np.testing.assert_allclose(got_grad.cpu().numpy(), feats.grad.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    cm, raw = qg.forward_channel_major(xyz, c, new_xyz, q, feats)
+    assert cm.shape == (48, int(qcnt.sum()) * 16) and cm.is_contiguous()
+    assert torch.equal(cm.view(48, -1, 16).permute(1, 0, 2), want)
