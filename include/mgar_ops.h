@@ -161,6 +161,35 @@ int mgar_query_group_stack_bwd(int B, int M, int C, int nsample, const float *gr
                                const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_features,
                                void *stream);
 
+/* ========== fused BatchNorm(train) + ReLU + max-over-nsample ========== */
+
+/* What follows the 1x1 convolution in every shared MLP of the SA / FP / RoI-pool modules:
+ * nn.BatchNorm2d -> nn.ReLU [-> F.max_pool2d over nsample]
+ * (pointnet2_batch/pointnet2_modules.py:37-45; pointnet2_stack/pointnet2_modules.py:96-104).
+ * Activations are x (B, C, P) contiguous, P = npoint*nsample columns.
+ * workspace: caller-allocated floats, mgar_bn_workspace_floats(B, C, P) of them.
+ *   train_stats : per-channel mean / invstd = 1/sqrt(var_biased + eps) of x; if running_* are
+ *                 non-NULL they receive the usual momentum update (unbiased variance).
+ *   act_fwd     : y = [relu](x * gamma*invstd + beta - mean*gamma*invstd)   (gamma/beta may be NULL)
+ *   act_maxpool_fwd : out (B,C,M) = max_s [relu](bn(x[b,c,m,s])), arg (B,C,M) uint8 = first arg-max
+ *   act_bwd     : dx, dgamma, dbeta of y = [relu](bn_train(x)) given dy (all fully written)
+ *   act_maxpool_bwd : the same when y was reduced by act_maxpool_fwd (dpool, pooled, arg) */
+int mgar_bn_workspace_floats(int B, int C, int P);
+int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace,
+                        float *mean, float *invstd, float *running_mean, float *running_var, void *stream);
+int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                    const float *gamma, const float *beta, int relu, float *y, void *stream);
+int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean,
+                            const float *invstd, const float *gamma, const float *beta, int relu, float *out,
+                            unsigned char *arg, void *stream);
+int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                    const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
+                    float *dbeta, float *dx, void *stream);
+int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x,
+                            int B, int C, int M, int nsample, const float *mean, const float *invstd,
+                            const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta,
+                            float *dx, void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).

@@ -44,6 +44,12 @@ _PROTOS = {
     "mgar_query_group_batch_bwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_query_group_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_query_group_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_bn_workspace_floats": [_I, _I, _I],
+    "mgar_bn_train_stats": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
+    "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
+    "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_dafm_attn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
@@ -92,6 +98,11 @@ def iptr(t):
 
 def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def raw(name, *args):
+    """Call an entry point whose return value is not a status code (e.g. a size query)."""
+    return _fns[name](*args)
 
 
 def call(name, *args):

@@ -1,0 +1,117 @@
+"""Fused BatchNorm(training statistics) + ReLU (+ max over nsample) on the HIP kernels of
+csrc/bn_act.hip -- the tail of every [Conv 1x1 -> BatchNorm -> ReLU] block of the shared MLPs
+(reference pointnet2_batch/pointnet2_modules.py:37-45 and friends).  Parameters and running
+statistics live in the caller's ``nn.BatchNormNd`` module, so state dicts are unchanged."""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+
+
+def _u8ptr(t):
+    return L.dev_ptr(t, torch.uint8)
+
+
+def _workspace(x, b, c, p):
+    return torch.empty((L.raw("mgar_bn_workspace_floats", b, c, p),), dtype=torch.float32, device=x.device)
+
+
+def _train_stats(x3, bn):
+    b, c, p = x3.shape
+    mean = torch.empty((c,), dtype=torch.float32, device=x3.device)
+    invstd = torch.empty_like(mean)
+    track = bn.track_running_stats and bn.running_mean is not None
+    L.call("mgar_bn_train_stats", L.fptr(x3), b, c, p, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
+           L.fptr(_workspace(x3, b, c, p)), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
+           L.fptr(bn.running_var) if track else None, L.stream_of(x3))
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return mean, invstd
+
+
+class _BnAct(Function):
+    """y = [relu](batch_norm_train(x)) for x (B, C, P); saves x (not y) for the backward."""
+
+    @staticmethod
+    def forward(ctx, x3, gamma, beta, mean, invstd, relu):
+        b, c, p = x3.shape
+        y = torch.empty_like(x3)
+        L.call("mgar_bn_act_fwd", L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), int(relu),
+               L.fptr(y), L.stream_of(x3))
+        ctx.save_for_backward(x3, gamma, beta, mean, invstd)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x3, gamma, beta, mean, invstd = ctx.saved_tensors
+        b, c, p = x3.shape
+        dx = torch.empty_like(x3)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        L.call("mgar_bn_act_bwd", L.fptr(dy.contiguous()), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+               L.fptr(beta), int(ctx.relu), L.fptr(_workspace(x3, b, c, p)), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx),
+               L.stream_of(x3))
+        return dx, dgamma, dbeta, None, None, None
+
+
+class _BnActMaxPool(Function):
+    """pooled (B, C, M) = max_s [relu](batch_norm_train(x))[b, c, m, s] for x (B, C, M, ns)."""
+
+    @staticmethod
+    def forward(ctx, x4, gamma, beta, mean, invstd, relu):
+        b, c, m, ns = x4.shape
+        out = torch.empty((b, c, m), dtype=torch.float32, device=x4.device)
+        arg = torch.empty((b, c, m), dtype=torch.uint8, device=x4.device)
+        L.call("mgar_bn_act_maxpool_fwd", L.fptr(x4), b, c, m, ns, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+               int(relu), L.fptr(out), _u8ptr(arg), L.stream_of(x4))
+        ctx.save_for_backward(x4, gamma, mean, invstd, out, arg)
+        ctx.relu = bool(relu)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpool, darg=None):
+        x4, gamma, mean, invstd, out, arg = ctx.saved_tensors
+        b, c, m, ns = x4.shape
+        dx = torch.empty_like(x4)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        L.call("mgar_bn_act_maxpool_bwd", L.fptr(dpool.contiguous()), L.fptr(out), _u8ptr(arg), L.fptr(x4), b, c, m, ns,
+               L.fptr(mean), L.fptr(invstd), L.fptr(gamma), int(ctx.relu), L.fptr(_workspace(x4, b, c, m * ns)),
+               L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), L.stream_of(x4))
+        return dx, dgamma, dbeta, None, None, None
+
+
+def _affine(bn, c, device):
+    if bn.affine:
+        return bn.weight, bn.bias
+    return torch.ones(c, device=device), torch.zeros(c, device=device)
+
+
+def _stats(x3, bn):
+    if bn.training or not bn.track_running_stats:
+        return _train_stats(x3, bn)
+    return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+
+
+def bn_act(x, bn, relu):
+    """[relu](bn(x)) for x (B, C, ...) contiguous on the device; ``bn`` is the nn.BatchNormNd module."""
+    x3 = x.contiguous().flatten(2) if x.dim() > 2 else x.contiguous().unsqueeze(-1)
+    if not bn.training and torch.is_grad_enabled() and x.requires_grad:
+        return None  # eval-mode backward: let the caller take the plain torch path
+    mean, invstd = _stats(x3, bn)
+    gamma, beta = _affine(bn, x3.shape[1], x.device)
+    return _BnAct.apply(x3, gamma, beta, mean, invstd, relu).view(x.shape)
+
+
+def bn_act_maxpool(x, bn, relu):
+    """max over the last axis of [relu](bn(x)) for x (B, C, M, ns) -> (B, C, M)."""
+    x4 = x.contiguous()
+    if x4.shape[-1] > 255 or (not bn.training and torch.is_grad_enabled() and x.requires_grad):
+        return None
+    mean, invstd = _stats(x4.flatten(2), bn)
+    gamma, beta = _affine(bn, x4.shape[1], x.device)
+    return _BnActMaxPool.apply(x4, gamma, beta, mean, invstd, relu)[0]

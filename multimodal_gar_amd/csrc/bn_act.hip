@@ -1,0 +1,424 @@
+// bn_act.hip -- BatchNorm (training statistics) + ReLU + max-over-nsample for the shared MLPs of
+// the set-abstraction / RoI-pooling modules, forward and backward, for gfx950.
+//
+// Replaces the per-layer torch chain of the reference's shared MLPs
+//   [Conv2d 1x1 -> BatchNorm2d -> ReLU] x k -> F.max_pool2d(kernel=[1, nsample])
+//   (pointnet2_batch/pointnet2_modules.py:37-45, :86-95; pointnet2_stack/pointnet2_modules.py:60-66,
+//    :96-104; voxel_pool_modules.py:44-58,:108-125)
+// for everything after the 1x1 convolution (which stays a library GEMM).
+//
+// Why a kernel: the activations are (B, C, P) with FEW channels (16..128) and HUGE P (up to
+// 3.3 M columns per sample).  MIOpen's spatial BatchNorm parallelises over channels, so C = 32
+// keeps 32 of 256 CUs busy (2.0 ms for a 0.42 GB tensor = 0.6 TB/s measured); ReLU and the max
+// over nsample are two more full passes.  Here
+//   * statistics: every (channel, 64 K-element chunk) is its own workgroup -> thousands of
+//     workgroups, fp32 partial sums, combined in double;
+//   * apply: one streaming pass y = relu(x * scale_c + shift_c), 16 B per lane;
+//   * the last layer never materialises y: relu(bn(x)) is reduced over nsample on the fly and only
+//     (B, C, M) maxima + 1-byte arg-max are written;
+//   * backward: one reduction pass (d_beta, d_gamma), one streaming pass for dx; after a fused
+//     max-pool the reduction touches only the arg-max elements.
+// All kernels are HBM-bound streaming passes: bytes per element are listed at each kernel.
+#include "common.hpp"
+
+namespace mgar {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_CHUNK = 65536;  // elements of one channel reduced by one workgroup
+
+__device__ __forceinline__ float block_sum(float v, float *scratch) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < BN_THREADS / 64; ++i) t += scratch[i];
+    return t;
+}
+
+// element e of channel c (0 <= e < B*P) lives at ((e / P) * C + c) * P + e % P
+__device__ __forceinline__ size_t chan_off(long long e, int c, int C, int P) {
+    const long long b = e / P;
+    return ((size_t)b * C + c) * P + (size_t)(e - b * P);
+}
+
+// ---- statistics: 4 B read per element -------------------------------------------------------
+// grid (nchunk, C).  partial[(c * nchunk + chunk) * 2 + {0,1}] = sum, sum of squares
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__restrict__ x, int B, int C, int P,
+                                                                float *__restrict__ partial) {
+    __shared__ float scratch[BN_THREADS / 64];
+    const int c = blockIdx.y;
+    const long long n = (long long)B * P;
+    const long long e0 = (long long)blockIdx.x * BN_CHUNK;
+    const long long e1 = min(e0 + BN_CHUNK, n);
+    float s = 0.f, q = 0.f;
+    if ((P & 3) == 0) {
+        for (long long e = e0 + (long long)threadIdx.x * 4; e < e1; e += BN_THREADS * 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + chan_off(e, c, C, P));
+            s += (v.x + v.y) + (v.z + v.w);
+            q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
+            const float v = x[chan_off(e, c, C, P)];
+            s += v;
+            q += v * v;
+        }
+    }
+    s = block_sum(s, scratch);
+    q = block_sum(q, scratch);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0] = s;
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1] = q;
+    }
+}
+
+// one thread per channel: combine the chunk sums in double, write mean / invstd, update running stats
+__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float eps, float momentum,
+                                   float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ running_mean,
+                                   float *__restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nchunk; ++i) {
+        s += (double)partial[((size_t)c * nchunk + i) * 2 + 0];
+        q += (double)partial[((size_t)c * nchunk + i) * 2 + 1];
+    }
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+}
+
+// ---- apply: 4 B read + 4 B written per element ----------------------------------------------
+// grid (ceil(P / (256*4*BN_APPLY_V)), B*C)
+constexpr int BN_APPLY_V = 4;  // float4 per thread
+
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__restrict__ x, int C, int P,
+                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                              const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                              float *__restrict__ y) {
+    const int row = blockIdx.y;
+    const int c = row % C;
+    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const float *xr = x + (size_t)row * P;
+    float *yr = y + (size_t)row * P;
+    const int base = blockIdx.x * (BN_THREADS * 4 * BN_APPLY_V);
+    if ((P & 3) == 0) {
+#pragma unroll
+        for (int u = 0; u < BN_APPLY_V; ++u) {
+            const int p = base + (u * BN_THREADS + threadIdx.x) * 4;
+            if (p < P) {
+                float4 v = *reinterpret_cast<const float4 *>(xr + p);
+                v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4 *>(yr + p) = v;
+            }
+        }
+    } else {
+        for (int p = base + threadIdx.x; p < min(P, base + BN_THREADS * 4 * BN_APPLY_V); p += BN_THREADS) {
+            float v = xr[p] * sc + sh;
+            yr[p] = RELU ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+// ---- apply + max over nsample: 4 B read per element, 5 B written per GROUP ---------------------
+// x (rows = B*C, M, NS) -> out (rows, M), arg (rows, M) uint8.  grid (ceil(M/256), rows)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restrict__ x, int C, int M, int NS,
+                                                            const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                            float *__restrict__ out, unsigned char *__restrict__ arg) {
+    const int row = blockIdx.y;
+    const int m = blockIdx.x * BN_THREADS + threadIdx.x;
+    if (m >= M) return;
+    const int c = row % C;
+    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const float *xr = x + ((size_t)row * M + m) * NS;
+    float best = -__builtin_inff();
+    int bi = 0;
+    if ((NS & 3) == 0) {
+        for (int s = 0; s < NS; s += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(xr + s);
+            const float a[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (a[u] > best) { best = a[u]; bi = s + u; }
+        }
+    } else {
+        for (int s = 0; s < NS; ++s) {
+            const float a = xr[s] * sc + sh;
+            if (a > best) { best = a; bi = s; }
+        }
+    }
+    out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
+    arg[(size_t)row * M + m] = (unsigned char)bi;
+}
+
+// ---- backward reduction: 8 B read per element ---------------------------------------------------
+// partial[(c*nchunk + chunk)*2 + {0,1}] = sum dz, sum dz * xhat    with dz = dy * [relu active]
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                    int B, int C, int P, const float *__restrict__ mean,
+                                                                    const float *__restrict__ invstd,
+                                                                    const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, float *__restrict__ partial) {
+    __shared__ float scratch[BN_THREADS / 64];
+    const int c = blockIdx.y;
+    const float mu = mean[c], is = invstd[c];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const long long n = (long long)B * P;
+    const long long e0 = (long long)blockIdx.x * BN_CHUNK;
+    const long long e1 = min(e0 + BN_CHUNK, n);
+    float s = 0.f, q = 0.f;
+    auto acc = [&](float xv, float d) {
+        const float xh = (xv - mu) * is;
+        if (RELU && !(xh * g + b > 0.f)) d = 0.f;
+        s += d;
+        q += d * xh;
+    };
+    if ((P & 3) == 0) {
+        for (long long e = e0 + (long long)threadIdx.x * 4; e < e1; e += BN_THREADS * 4) {
+            const size_t o = chan_off(e, c, C, P);
+            const float4 xv = *reinterpret_cast<const float4 *>(x + o);
+            const float4 dv = *reinterpret_cast<const float4 *>(dy + o);
+            acc(xv.x, dv.x); acc(xv.y, dv.y); acc(xv.z, dv.z); acc(xv.w, dv.w);
+        }
+    } else {
+        for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
+            const size_t o = chan_off(e, c, C, P);
+            acc(x[o], dy[o]);
+        }
+    }
+    s = block_sum(s, scratch);
+    q = block_sum(q, scratch);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0] = s;
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1] = q;
+    }
+}
+
+// after a fused max-pool only the arg-max element of every group carries gradient:
+// 13 B read per GROUP.  grid (nchunk over B*M, C)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const float *__restrict__ dpool,
+                                                                        const float *__restrict__ pooled,
+                                                                        const unsigned char *__restrict__ arg,
+                                                                        const float *__restrict__ x, int B, int C, int M, int NS,
+                                                                        const float *__restrict__ mean,
+                                                                        const float *__restrict__ invstd,
+                                                                        float *__restrict__ partial) {
+    __shared__ float scratch[BN_THREADS / 64];
+    const int c = blockIdx.y;
+    const float mu = mean[c], is = invstd[c];
+    const long long n = (long long)B * M;
+    const long long e0 = (long long)blockIdx.x * BN_CHUNK;
+    const long long e1 = min(e0 + BN_CHUNK, n);
+    float s = 0.f, q = 0.f;
+    for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
+        const size_t o = chan_off(e, c, C, M);
+        float d = dpool[o];
+        if (RELU && !(pooled[o] > 0.f)) d = 0.f;
+        const float xh = (x[o * NS + arg[o]] - mu) * is;
+        s += d;
+        q += d * xh;
+    }
+    s = block_sum(s, scratch);
+    q = block_sum(q, scratch);
+    if (threadIdx.x == 0) {
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0] = s;
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1] = q;
+    }
+}
+
+// d_beta[c] (+)= sum dz ; d_gamma[c] (+)= sum dz*xhat ; coef[c] = {mean dz, mean dz*xhat}
+__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float *__restrict__ dgamma,
+                                       float *__restrict__ dbeta, float *__restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < nchunk; ++i) {
+        s += (double)partial[((size_t)c * nchunk + i) * 2 + 0];
+        q += (double)partial[((size_t)c * nchunk + i) * 2 + 1];
+    }
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)q;
+    coef[2 * c + 0] = (float)(s / n);
+    coef[2 * c + 1] = (float)(q / n);
+}
+
+// ---- backward apply: dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)) ----------------
+// 8 B read + 4 B written per element.  grid (ceil(P/(256*4)), B*C)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, int C,
+                                                                  int P, const float *__restrict__ mean,
+                                                                  const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta, const float *__restrict__ coef,
+                                                                  float *__restrict__ dx) {
+    const int row = blockIdx.y;
+    const int c = row % C;
+    const float mu = mean[c], is = invstd[c];
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float m0 = coef[2 * c], m1 = coef[2 * c + 1];
+    const float k = g * is;
+    const size_t ro = (size_t)row * P;
+    auto one = [&](float xv, float d) {
+        const float xh = (xv - mu) * is;
+        if (RELU && !(xh * g + b > 0.f)) d = 0.f;
+        return k * (d - m0 - xh * m1);
+    };
+    if ((P & 3) == 0) {
+        const int p0 = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
+        if (p0 >= P) return;
+        const float4 xv = *reinterpret_cast<const float4 *>(x + ro + p0);
+        const float4 dv = *reinterpret_cast<const float4 *>(dy + ro + p0);
+        float4 r;
+        r.x = one(xv.x, dv.x); r.y = one(xv.y, dv.y); r.z = one(xv.z, dv.z); r.w = one(xv.w, dv.w);
+        *reinterpret_cast<float4 *>(dx + ro + p0) = r;
+    } else {
+        const int p0 = blockIdx.x * BN_THREADS + threadIdx.x;
+        if (p0 < P) dx[ro + p0] = one(x[ro + p0], dy[ro + p0]);
+    }
+}
+
+// after a fused max-pool: 4 B read + 4 B written per element (+ 9 B per group, cached).
+// lanes run along the flat (m, s) index, 4 elements per lane.  grid (ceil(M*NS/(256*4)), B*C)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const float *__restrict__ dpool,
+                                                                      const float *__restrict__ pooled,
+                                                                      const unsigned char *__restrict__ arg,
+                                                                      const float *__restrict__ x, int C, int M, int NS,
+                                                                      const float *__restrict__ mean,
+                                                                      const float *__restrict__ invstd,
+                                                                      const float *__restrict__ gamma,
+                                                                      const float *__restrict__ coef, float *__restrict__ dx) {
+    const int row = blockIdx.y;
+    const int c = row % C;
+    const float mu = mean[c], is = invstd[c];
+    const float k = (gamma ? gamma[c] : 1.f) * is;
+    const float m0 = coef[2 * c], m1 = coef[2 * c + 1];
+    const long long P = (long long)M * NS;
+    const size_t ro = (size_t)row * P;
+    const size_t go = (size_t)row * M;
+    const int step = (NS & 3) == 0 ? 4 : 1;
+    const long long p0 = ((long long)blockIdx.x * BN_THREADS + threadIdx.x) * step;
+    if (p0 >= P) return;
+    const int m = (int)(p0 / NS), s0 = (int)(p0 - (long long)m * NS);
+    float d = dpool[go + m];
+    if (RELU && !(pooled[go + m] > 0.f)) d = 0.f;
+    const int a = arg[go + m];
+    if (step == 4) {
+        const float4 xv = *reinterpret_cast<const float4 *>(x + ro + p0);
+        float4 r;
+        r.x = k * ((s0 + 0 == a ? d : 0.f) - m0 - (xv.x - mu) * is * m1);
+        r.y = k * ((s0 + 1 == a ? d : 0.f) - m0 - (xv.y - mu) * is * m1);
+        r.z = k * ((s0 + 2 == a ? d : 0.f) - m0 - (xv.z - mu) * is * m1);
+        r.w = k * ((s0 + 3 == a ? d : 0.f) - m0 - (xv.w - mu) * is * m1);
+        *reinterpret_cast<float4 *>(dx + ro + p0) = r;
+    } else {
+        dx[ro + p0] = k * ((s0 == a ? d : 0.f) - m0 - (x[ro + p0] - mu) * is * m1);
+    }
+}
+
+static inline int bn_nchunk(int B, int P) { return (int)(((long long)B * P + BN_CHUNK - 1) / BN_CHUNK); }
+
+}  // namespace mgar
+
+using namespace mgar;
+
+#define BN_API extern "C" __attribute__((visibility("default")))
+
+BN_API int mgar_bn_workspace_floats(int B, int C, int P) {
+    if (B < 0 || C < 0 || P < 0) return MGAR_EINVAL;
+    return 2 * C * (bn_nchunk(B, P) > 0 ? bn_nchunk(B, P) : 1) + 2 * C;
+}
+
+static int bn_sizes_ok(int B, int C, long long P) { return B >= 0 && C >= 0 && P >= 0 && (long long)B * C <= 65535LL * 32768; }
+
+BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean,
+                               float *invstd, float *running_mean, float *running_var, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_train_stats: bad sizes");
+    if ((long long)B * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && workspace && mean && invstd, "bn_train_stats: null pointer");
+    MGAR_REQUIRE(C <= 65535, "bn_train_stats: C > 65535");
+    const int nchunk = bn_nchunk(B, P);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, workspace);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, eps,
+                       momentum, mean, invstd, running_mean, running_var);
+    return check_launch("bn_train_stats: launch failed");
+}
+
+BN_API int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
+                           const float *beta, int relu, float *y, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_fwd: bad sizes");
+    if ((long long)B * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && y && mean && invstd, "bn_act_fwd: null pointer");
+    MGAR_REQUIRE((long long)B * C <= 65535, "bn_act_fwd: B*C > 65535");
+    dim3 grid(ceil_div(P, BN_THREADS * 4 * BN_APPLY_V), B * C);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
+    return check_launch("bn_act_fwd: launch failed");
+}
+
+BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean, const float *invstd,
+                                   const float *gamma, const float *beta, int relu, float *out, unsigned char *arg,
+                                   void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_fwd: bad sizes");
+    if ((long long)B * C * M == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && out && arg && mean && invstd, "bn_act_maxpool_fwd: null pointer");
+    MGAR_REQUIRE((long long)B * C <= 65535, "bn_act_maxpool_fwd: B*C > 65535");
+    dim3 grid(ceil_div(M, BN_THREADS), B * C);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
+    else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
+    return check_launch("bn_act_maxpool_fwd: launch failed");
+}
+
+BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                           const float *gamma, const float *beta, int relu, float *workspace, float *dgamma, float *dbeta,
+                           float *dx, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_bwd: bad sizes");
+    if ((long long)B * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx, "bn_act_bwd: null pointer");
+    MGAR_REQUIRE(C <= 65535 && (long long)B * C <= 65535, "bn_act_bwd: C or B*C > 65535");
+    const int nchunk = bn_nchunk(B, P);
+    float *coef = workspace + (size_t)2 * C * nchunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    else hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
+    dim3 grid(ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)), B * C);
+    if (relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    return check_launch("bn_act_bwd: launch failed");
+}
+
+BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x, int B, int C,
+                                   int M, int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
+                                   float *workspace, float *dgamma, float *dbeta, float *dx, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_bwd: bad sizes");
+    if ((long long)B * C * M == 0) return MGAR_OK;
+    MGAR_REQUIRE(dpool && pooled && arg && x && mean && invstd && workspace && dx, "bn_act_maxpool_bwd: null pointer");
+    MGAR_REQUIRE(C <= 65535 && (long long)B * C <= 65535, "bn_act_maxpool_bwd: C or B*C > 65535");
+    const int nchunk = bn_nchunk(B, M);
+    float *coef = workspace + (size_t)2 * C * nchunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) hipLaunchKernelGGL(bn_max_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
+    else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
+    // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
+    dim3 grid(ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)), B * C);
+    if (relu) hipLaunchKernelGGL(bn_max_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
+    else hipLaunchKernelGGL(bn_max_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
+    return check_launch("bn_act_maxpool_bwd: launch failed");
+}

@@ -13,8 +13,12 @@ import torch.nn as nn
 
 def conv1x1(conv, x):
     """y[b, o, ...] = sum_i W[o, i] x[b, i, ...] (+ bias) for a kernel-size-1 ConvNd."""
-    w = conv.weight.view(conv.out_channels, conv.in_channels)
-    y = torch.matmul(w, x.flatten(2))
+    w = conv.weight.view(1, conv.out_channels, conv.in_channels)
+    x3 = x.flatten(2)
+    # 3-D @ 3-D: the result is produced directly as (B, C_out, P).  (A 2-D weight makes torch fold
+    # the batch into the GEMM's rows and hand back a TRANSPOSED view, which the next op then
+    # materialises with a slow strided copy of the whole activation.)
+    y = torch.bmm(w.expand(x3.shape[0], -1, -1), x3)
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1)
     return y.view(x.shape[0], conv.out_channels, *x.shape[2:])
@@ -25,10 +29,48 @@ def _is_pointwise(m):
         and all(s == 1 for s in m.stride) and all(p == 0 for p in m.padding) and m.groups == 1
 
 
+_BN_TYPES = (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)
+
+
 class PointwiseSequential(nn.Sequential):
-    """nn.Sequential (same state-dict keys) whose kernel-size-1 convolutions run as GEMMs."""
+    """nn.Sequential (same state-dict keys) for the shared MLPs: kernel-size-1 convolutions run as
+    GEMMs, and on the device every BatchNorm [+ ReLU] that follows runs in the fused HIP kernels of
+    csrc/bn_act.hip; ``forward_maxpool`` additionally folds the max over the last axis (nsample)
+    into the last BatchNorm + ReLU so that activation is never written."""
+
+    def _run(self, x, pool_last):
+        from . import bn_ops
+        layers = list(self)
+        i, n = 0, len(layers)
+        pooled = False
+        while i < n:
+            layer = layers[i]
+            if _is_pointwise(layer):
+                x = conv1x1(layer, x)
+                i += 1
+            elif isinstance(layer, _BN_TYPES) and x.is_cuda:
+                relu = i + 1 < n and isinstance(layers[i + 1], nn.ReLU)
+                last = i + (2 if relu else 1) >= n
+                y = None
+                if pool_last and last and x.dim() == 4:
+                    y = bn_ops.bn_act_maxpool(x, layer, relu)
+                    pooled = y is not None
+                if y is None:
+                    y = bn_ops.bn_act(x, layer, relu)
+                if y is None:            # eval-mode backward etc.: plain torch
+                    y = layer(x)
+                    relu = False
+                x = y
+                i += 2 if relu else 1
+            else:
+                x = layer(x)
+                i += 1
+        return x, pooled
 
     def forward(self, x):
-        for layer in self:
-            x = conv1x1(layer, x) if _is_pointwise(layer) else layer(x)
-        return x
+        return self._run(x, False)[0]
+
+    def forward_maxpool(self, x):
+        """(B, C, M, ns) -> (B, C', M): the MLP followed by a max over ns."""
+        y, pooled = self._run(x, True)
+        return y if pooled else y.max(dim=3).values

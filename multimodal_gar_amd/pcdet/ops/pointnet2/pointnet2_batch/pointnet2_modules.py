@@ -50,7 +50,10 @@ class _PointnetSAModuleBase(nn.Module):
         per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped = grouper(xyz, new_xyz, features)          # (B, C', npoint, nsample)
-            per_scale.append(pool_over_samples(mlp(grouped), self.pool_method))
+            if self.pool_method == 'max_pool':
+                per_scale.append(mlp.forward_maxpool(grouped))             # BN + ReLU + max fused on the device
+            else:
+                per_scale.append(pool_over_samples(mlp(grouped), self.pool_method))
         return new_xyz, torch.cat(per_scale, dim=1)
 
 

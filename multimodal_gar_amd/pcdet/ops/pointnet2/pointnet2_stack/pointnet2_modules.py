@@ -64,11 +64,11 @@ class StackSAModuleMSG(nn.Module):
         per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             grouped, _ = grouper.forward_channel_major(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
-            x = mlp(grouped.view(1, grouped.shape[0], new_xyz.shape[0], -1))                # (1, C', M, nsample)
+            grouped = grouped.view(1, grouped.shape[0], new_xyz.shape[0], -1)              # (1, C, M, nsample)
             if self.pool_method == 'max_pool':
-                x = x.max(dim=3).values
+                x = mlp.forward_maxpool(grouped)                                            # (1, C', M)
             elif self.pool_method == 'avg_pool':
-                x = x.mean(dim=3)
+                x = mlp(grouped).mean(dim=3)
             else:
                 raise NotImplementedError
             per_scale.append(x.squeeze(0).permute(1, 0))                                    # (M, C')
