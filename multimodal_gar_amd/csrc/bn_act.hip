@@ -95,7 +95,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partial, int nchunk
 }
 
 // ---- apply: 4 B read + 4 B written per element ----------------------------------------------
-// grid (ceil(P / (256*4*BN_APPLY_V)), B*C)
+// grid (B*C rows, ceil(P / (256*4*BN_APPLY_V)))
 constexpr int BN_APPLY_V = 4;  // float4 per thread
 
 template <bool RELU>
@@ -103,13 +103,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
                                                               float *__restrict__ y) {
-    const int row = blockIdx.y;
+    const int row = blockIdx.x;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
     const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
     const float *xr = x + (size_t)row * P;
     float *yr = y + (size_t)row * P;
-    const int base = blockIdx.x * (BN_THREADS * 4 * BN_APPLY_V);
+    const int base = blockIdx.y * (BN_THREADS * 4 * BN_APPLY_V);
     if ((P & 3) == 0) {
 #pragma unroll
         for (int u = 0; u < BN_APPLY_V; ++u) {
@@ -136,8 +136,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restr
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
                                                             float *__restrict__ out, unsigned char *__restrict__ arg) {
-    const int row = blockIdx.y;
-    const int m = blockIdx.x * BN_THREADS + threadIdx.x;
+    const int row = blockIdx.x;
+    const int m = blockIdx.y * BN_THREADS + threadIdx.x;
     if (m >= M) return;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
                                                                   const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                                   const float *__restrict__ beta, const float *__restrict__ coef,
                                                                   float *__restrict__ dx) {
-    const int row = blockIdx.y;
+    const int row = blockIdx.x;
     const int c = row % C;
     const float mu = mean[c], is = invstd[c];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
         return k * (d - m0 - xh * m1);
     };
     if ((P & 3) == 0) {
-        const int p0 = (blockIdx.x * BN_THREADS + threadIdx.x) * 4;
+        const int p0 = (blockIdx.y * BN_THREADS + threadIdx.x) * 4;
         if (p0 >= P) return;
         const float4 xv = *reinterpret_cast<const float4 *>(x + ro + p0);
         const float4 dv = *reinterpret_cast<const float4 *>(dy + ro + p0);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
         r.x = one(xv.x, dv.x); r.y = one(xv.y, dv.y); r.z = one(xv.z, dv.z); r.w = one(xv.w, dv.w);
         *reinterpret_cast<float4 *>(dx + ro + p0) = r;
     } else {
-        const int p0 = blockIdx.x * BN_THREADS + threadIdx.x;
+        const int p0 = blockIdx.y * BN_THREADS + threadIdx.x;
         if (p0 < P) dx[ro + p0] = one(x[ro + p0], dy[ro + p0]);
     }
 }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const floa
                                                                       const float *__restrict__ invstd,
                                                                       const float *__restrict__ gamma,
                                                                       const float *__restrict__ coef, float *__restrict__ dx) {
-    const int row = blockIdx.y;
+    const int row = blockIdx.x;
     const int c = row % C;
     const float mu = mean[c], is = invstd[c];
     const float k = (gamma ? gamma[c] : 1.f) * is;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const floa
     const size_t ro = (size_t)row * P;
     const size_t go = (size_t)row * M;
     const int step = (NS & 3) == 0 ? 4 : 1;
-    const long long p0 = ((long long)blockIdx.x * BN_THREADS + threadIdx.x) * step;
+    const long long p0 = ((long long)blockIdx.y * BN_THREADS + threadIdx.x) * step;
     if (p0 >= P) return;
     const int m = (int)(p0 / NS), s0 = (int)(p0 - (long long)m * NS);
     float d = dpool[go + m];
@@ -341,7 +341,7 @@ BN_API int mgar_bn_workspace_floats(int B, int C, int P) {
     return 2 * C * (bn_nchunk(B, P) > 0 ? bn_nchunk(B, P) : 1) + 2 * C;
 }
 
-static int bn_sizes_ok(int B, int C, long long P) { return B >= 0 && C >= 0 && P >= 0 && (long long)B * C <= 65535LL * 32768; }
+static int bn_sizes_ok(int B, int C, long long P) { return B >= 0 && C >= 0 && P >= 0 && (long long)B * C <= 2147483647LL; }
 
 BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean,
                                float *invstd, float *running_mean, float *running_var, void *stream) {
@@ -362,8 +362,8 @@ BN_API int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mea
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_fwd: bad sizes");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(x && y && mean && invstd, "bn_act_fwd: null pointer");
-    MGAR_REQUIRE((long long)B * C <= 65535, "bn_act_fwd: B*C > 65535");
-    dim3 grid(ceil_div(P, BN_THREADS * 4 * BN_APPLY_V), B * C);
+    MGAR_REQUIRE((long long)P <= 65535LL * BN_THREADS * 4, "bn_act_fwd: P too large");
+    dim3 grid(B * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
     hipStream_t st = (hipStream_t)stream;
     if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
     else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
@@ -376,8 +376,8 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_fwd: bad sizes");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(x && out && arg && mean && invstd, "bn_act_maxpool_fwd: null pointer");
-    MGAR_REQUIRE((long long)B * C <= 65535, "bn_act_maxpool_fwd: B*C > 65535");
-    dim3 grid(ceil_div(M, BN_THREADS), B * C);
+    MGAR_REQUIRE((long long)M <= 65535LL * BN_THREADS, "bn_act_maxpool_fwd: M too large");
+    dim3 grid(B * C, ceil_div(M, BN_THREADS));
     hipStream_t st = (hipStream_t)stream;
     if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
     else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
@@ -390,14 +390,14 @@ BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P,
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_bwd: bad sizes");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx, "bn_act_bwd: null pointer");
-    MGAR_REQUIRE(C <= 65535 && (long long)B * C <= 65535, "bn_act_bwd: C or B*C > 65535");
+    MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS, "bn_act_bwd: C > 65535 or P too large");
     const int nchunk = bn_nchunk(B, P);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
     if (relu) hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
-    dim3 grid(ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)), B * C);
+    dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
     if (relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
     return check_launch("bn_act_bwd: launch failed");
@@ -409,7 +409,7 @@ BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, cons
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_bwd: bad sizes");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(dpool && pooled && arg && x && mean && invstd && workspace && dx, "bn_act_maxpool_bwd: null pointer");
-    MGAR_REQUIRE(C <= 65535 && (long long)B * C <= 65535, "bn_act_maxpool_bwd: C or B*C > 65535");
+    MGAR_REQUIRE(C <= 65535 && (long long)M * nsample <= 65535LL * BN_THREADS, "bn_act_maxpool_bwd: C > 65535 or M*nsample too large");
     const int nchunk = bn_nchunk(B, M);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
@@ -417,7 +417,7 @@ BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, cons
     else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
-    dim3 grid(ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)), B * C);
+    dim3 grid(B * C, ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)));
     if (relu) hipLaunchKernelGGL(bn_max_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
     else hipLaunchKernelGGL(bn_max_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
     return check_launch("bn_act_maxpool_bwd: launch failed");

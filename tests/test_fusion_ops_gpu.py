@@ -158,7 +158,7 @@ def test_giou_and_pairwise_against_numpy(oracle):
 
 # --------------------------------------------------------------------- fused BN + ReLU (+ max)
 @pytest.mark.parametrize("shape,relu", [((3, 16, 700, 16), True), ((1, 32, 5000, 16), True), ((4, 7, 33), False),
-                                        ((2, 5, 9, 3, 3), True), ((120, 64, 64, 32), True)])
+                                        ((2, 5, 9, 3, 3), True), ((120, 64, 64, 32), True), ((3000, 24, 6, 6, 6), False)])
 def test_bn_act_matches_torch(shape, relu):
     from multimodal_gar_amd import bn_ops
     torch.manual_seed(len(shape) + shape[1])
@@ -216,7 +216,8 @@ def test_shared_mlp_fused_path_equals_layerwise_torch():
     from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch.pointnet2_modules import shared_mlp_2d
     torch.manual_seed(4)
     mlp = shared_mlp_2d([7, 16, 32]).cuda().train()
-    plain = torch.nn.Sequential(*[m for m in mlp]).double().cpu()
+    import copy
+    plain = torch.nn.Sequential(*[copy.deepcopy(m) for m in mlp]).double().cpu()
     plain.load_state_dict({k: v.double().cpu() if v.is_floating_point() else v.cpu() for k, v in mlp.state_dict().items()})
     plain.train()
     x = torch.randn(3, 7, 200, 16).cuda().requires_grad_(True)
