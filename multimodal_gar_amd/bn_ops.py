@@ -23,8 +23,9 @@ def _train_stats(x3, bn):
     mean = torch.empty((c,), dtype=torch.float32, device=x3.device)
     invstd = torch.empty_like(mean)
     track = bn.track_running_stats and bn.running_mean is not None
+    ws = _workspace(x3, b, c, p)
     L.call("mgar_bn_train_stats", L.fptr(x3), b, c, p, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
-           L.fptr(_workspace(x3, b, c, p)), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
+           L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
            L.fptr(bn.running_var) if track else None, L.stream_of(x3))
     if track and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
@@ -51,9 +52,11 @@ class _BnAct(Function):
         b, c, p = x3.shape
         dx = torch.empty_like(x3)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
-        L.call("mgar_bn_act_bwd", L.fptr(dy.contiguous()), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
-               L.fptr(beta), int(ctx.relu), L.fptr(_workspace(x3, b, c, p)), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx),
-               L.stream_of(x3))
+        # every tensor whose pointer is passed stays bound to a name until the call returns: a
+        # temporary freed mid-expression can be handed out again by the caching allocator
+        dy_c, ws = dy.contiguous(), _workspace(x3, b, c, p)
+        L.call("mgar_bn_act_bwd", L.fptr(dy_c), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+               L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), L.stream_of(x3))
         return dx, dgamma, dbeta, None, None, None
 
 
@@ -79,9 +82,10 @@ class _BnActMaxPool(Function):
         b, c, m, ns = x4.shape
         dx = torch.empty_like(x4)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        L.call("mgar_bn_act_maxpool_bwd", L.fptr(dpool.contiguous()), L.fptr(out), _u8ptr(arg), L.fptr(x4), b, c, m, ns,
-               L.fptr(mean), L.fptr(invstd), L.fptr(gamma), int(ctx.relu), L.fptr(_workspace(x4, b, c, m * ns)),
-               L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), L.stream_of(x4))
+        dpool_c, ws = dpool.contiguous(), _workspace(x4, b, c, m * ns)
+        L.call("mgar_bn_act_maxpool_bwd", L.fptr(dpool_c), L.fptr(out), _u8ptr(arg), L.fptr(x4), b, c, m, ns,
+               L.fptr(mean), L.fptr(invstd), L.fptr(gamma), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta),
+               L.fptr(dx), L.stream_of(x4))
         return dx, dgamma, dbeta, None, None, None
 
 

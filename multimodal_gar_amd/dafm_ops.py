@@ -29,8 +29,9 @@ class _DafmAttention(Function):
         rows, d = q.shape
         gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         gmat = torch.empty_like(att)
+        grad_out = grad_out.contiguous()
         L.call("mgar_dafm_attn_bwd", scene_off.numel() - 1, rows, d, L.iptr(scene_off), L.iptr(de_off), L.fptr(q),
-               L.fptr(k), L.fptr(v), L.fptr(de_flat), sigma, scale, L.fptr(att), L.fptr(grad_out.contiguous()),
+               L.fptr(k), L.fptr(v), L.fptr(de_flat), sigma, scale, L.fptr(att), L.fptr(grad_out),
                L.fptr(gmat), L.fptr(gq), L.fptr(gk), L.fptr(gv), L.stream_of(q))
         return gq, gk, gv, None, None, None, None, None
 

@@ -48,8 +48,9 @@ class _GatAggregate(Function):
         gxl = torch.zeros_like(xl)
         gxr = torch.empty_like(xr)
         gatt = torch.zeros_like(att)
+        grad_out = grad_out.contiguous()
         L.call("mgar_gatv2_bwd", n, heads, c, L.iptr(rowptr), L.iptr(col), L.fptr(xl), L.fptr(xr), L.fptr(att), slope,
-               L.fptr(edge_scale) if has_scale else None, L.fptr(alpha), L.fptr(grad_out.contiguous()), L.fptr(gxl),
+               L.fptr(edge_scale) if has_scale else None, L.fptr(alpha), L.fptr(grad_out), L.fptr(gxl),
                L.fptr(gxr), L.fptr(gatt), L.stream_of(xl))
         return gxl, gxr, gatt, None, None, None, None, None
 

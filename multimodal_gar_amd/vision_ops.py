@@ -42,7 +42,8 @@ class _RoIAlign(Function):
         grad_in = None
         if ctx.needs_input_grad[0]:
             grad_in = torch.zeros((n, c, h, w), dtype=torch.float32, device=grad_out.device)
-            L.call("mgar_roi_align_bwd", L.fptr(grad_out.contiguous()), n, c, h, w, L.fptr(rois), rois.shape[0], ph, pw,
+            grad_out = grad_out.contiguous()
+            L.call("mgar_roi_align_bwd", L.fptr(grad_out), n, c, h, w, L.fptr(rois), rois.shape[0], ph, pw,
                    scale, sr, al, L.fptr(grad_in), L.stream_of(grad_out))
         return grad_in, None, None, None, None, None, None
 

@@ -201,7 +201,7 @@ def test_bn_act_maxpool_matches_torch(shape):
     x = torch.randn(shape).cuda().requires_grad_(True)
     y = bn_ops.bn_act_maxpool(x, bn, True)
     assert y.shape == shape[:3]
-    g = torch.randn_like(y)
+    g = torch.randn(shape[0], shape[2], shape[1], device="cuda").transpose(1, 2)   # NON-contiguous upstream gradient
     y.backward(g)
     xd = x.detach().double().cpu().requires_grad_(True)
     yr = torch.relu(ref(xd)).max(dim=3).values
