@@ -134,3 +134,68 @@ def test_clip_model_forward_gpu_vs_cpu_backend():
     assert len(got) == 16
     for a, b in zip(got, want):
         close(a, b, rtol=5e-4, atol=1e-5)
+
+
+def _reference_style_batch(seed, n_actors, n_points, route, ds):
+    """The 12-tuple the reference's collate_batch produces (dataloader.py:296-419), batch size 1,
+    with a pcdet data_dict holding NUMPY arrays (load_data_to_gpu moves them)."""
+    from multimodal_gar_amd import synthetic as S, workload as W
+    sc = S.scene_batch(seed, 1, n_actors, n_points, num_boxes=n_actors + 2, height=64, width=96)
+    rng = np.random.default_rng(seed)
+    images = torch.from_numpy(S.images(seed, 1, 5, 64, 96))
+    bboxes = torch.from_numpy(sc["bboxes"]); b3 = torch.from_numpy(sc["bboxes3d"]); pid = torch.from_numpy(sc["person_id"])
+    pts = sc["points"]
+    if route == "pointnet2":
+        data = {"batch_size": 1, "points": np.concatenate([np.zeros((n_points, 1), np.float32), pts[0]], 1),
+                "gt_boxes": sc["bboxes3d"][:, :n_actors]}
+    else:
+        vd = W.voxelize_batch(torch.from_numpy(pts), ds)
+        data = {"batch_size": 1, "voxels": vd["voxels"].numpy(), "voxel_num_points": vd["voxel_num_points"].numpy(),
+                "voxel_coords": vd["voxel_coords"].numpy().astype(np.float32), "gt_boxes": sc["bboxes3d"][:, :n_actors]}
+    return (images, bboxes, None, b3, None, pid, None, None, None, None, None, data)
+
+
+@pytest.mark.parametrize("route", ["pointnet2", "voxel"])
+def test_gar_fusion_all_forward_reference_call_shape(route):
+    """GAR_Fusion_ALL.forward(batch) exactly as train_func.py:111 calls it: 12-tuple in, 16-tuple out,
+    on both LiDAR routes; GPU (HIP kernels) vs CPU (oracle backend)."""
+    from multimodal_gar_amd import workload as W
+    from multimodal_gar_amd.model.gat_model import GAR_Fusion_ALL
+    from oracle.cpu_backend import use_cpu_oracle
+    ds = W.SyntheticDataset()
+    cfg = W.model_cfg(4, 2048, gat=True, route=route)
+    cfg.DATALOADER.train.augmentation.num_boxes = 6
+    net = fill_deterministic(GAR_Fusion_ALL(cfg, ds), seed=21).eval()
+    batch = _reference_style_batch(4, 4, 2048, route, ds)
+    import unittest.mock as mock
+    with use_cpu_oracle(), torch.no_grad(), mock.patch("multimodal_gar_amd.model.gat_model.load_data_to_gpu", lambda d: d.update(
+            {k: torch.from_numpy(v).float() for k, v in d.items() if isinstance(v, np.ndarray)})):
+        want = net(tuple(copy.deepcopy(batch)))
+    gnet = copy.deepcopy(net).cuda()
+    gb = list(copy.deepcopy(batch))
+    for i in (0, 1, 3, 5):
+        gb[i] = gb[i].cuda()
+    with torch.no_grad():
+        got = gnet(tuple(gb))
+    assert len(got) == 16 and got[0].shape == (1, 6, 6) and got[-1].shape == (1, 1)
+    for a, b in zip(got, want):
+        close(a, b, rtol=5e-4, atol=1e-5)
+
+
+def test_social_grouping_model_forward():
+    from multimodal_gar_amd import workload as W
+    from multimodal_gar_amd.model.sg_model import SocialGrouping_model
+    from oracle.cpu_backend import use_cpu_oracle
+    cfg = W.model_cfg(4, 1024, gat=True)
+    net = fill_deterministic(SocialGrouping_model(cfg, N=2), seed=22).eval()
+    batch = _reference_style_batch(6, 4, 1024, "pointnet2", None)
+    with use_cpu_oracle(), torch.no_grad():
+        want = net(tuple(copy.deepcopy(batch)))
+    gnet = copy.deepcopy(net).cuda()
+    gb = list(copy.deepcopy(batch))
+    for i in (0, 1, 3, 5):
+        gb[i] = gb[i].cuda()
+    with torch.no_grad():
+        got = gnet(tuple(gb))
+    assert got.shape == (4, 4) and torch.allclose(torch.diagonal(got), torch.ones(4, device="cuda"))
+    close(got, want, rtol=5e-4)
