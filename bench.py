@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark (slow first step)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the RGB and LiDAR branches on one stream")
     ap.add_argument("--phases", action="store_true", help="print a synchronised per-phase timing of one step")
     return ap.parse_args()
 
@@ -196,6 +197,7 @@ def main():
     torch.backends.cudnn.benchmark = bool(args.miopen_find)   # MIOpen find mode for the I3D convolutions
     log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
     step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp)
+    step.module.overlap_branches = not args.no_overlap
     batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
 
     def barrier():

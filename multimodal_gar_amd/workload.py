@@ -118,6 +118,8 @@ class ClipModel(nn.Module):
         self.dataset = SyntheticDataset()
         self.net = GAR_Fusion_ALL(self.cfg, self.dataset)
         self.net.GAR_model.uniform_actor_count = n_actors
+        self.overlap_branches = True
+        self._side_stream = None
 
     # ---- RGB: one I3D pass per clip (batch 1, like the reference) ---------------------------------
     def rgb_tokens(self, images, bboxes):
@@ -155,8 +157,22 @@ class ClipModel(nn.Module):
 
     def forward(self, batch):
         b, t, a = batch["n_clips"], batch["n_frames"], self.n_actors
-        rgb = self.rgb_tokens(batch["images"], batch["bboxes"])                     # (B, A, 512)
-        lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])               # (B*T, A, 512)
+        if batch["images"].is_cuda and self.overlap_branches:
+            # The RGB branch (I3D convolutions: MFMA-heavy) and the LiDAR branch (HBM-bound kernels)
+            # are independent until the fusion model: run the RGB branch on a side HIP stream so the
+            # two overlap on the chip.  Autograd replays each op's backward on its forward stream.
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side_stream.wait_stream(main)
+            with torch.cuda.stream(self._side_stream):
+                rgb = self.rgb_tokens(batch["images"], batch["bboxes"])             # (B, A, 512)
+            lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])           # (B*T, A, 512)
+            main.wait_stream(self._side_stream)
+            rgb.record_stream(main)
+        else:
+            rgb = self.rgb_tokens(batch["images"], batch["bboxes"])
+            lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])
         rgb_s = rgb[:, None].expand(b, t, a, rgb.shape[-1]).reshape(b * t, a, -1)   # every frame-scene of a clip
         pad = lambda x: torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2])], 1)    # noqa: E731  -> MNP = A + 1
         bb2 = batch["bboxes"][:, None].expand(b, t, a + 1, 4).reshape(b * t, a + 1, 4)
