@@ -161,6 +161,27 @@ int mgar_query_group_stack_bwd(int B, int M, int C, int nsample, const float *gr
                                const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_features,
                                void *stream);
 
+/* "Project, then group": the first shared-MLP layer is linear, so
+ *   W [rel_xyz ; feat_j] = W_xyz rel_xyz + (W_f feat)_j
+ * i.e. the feature half can be applied to the N un-grouped points (zf = W_f features, a small GEMM)
+ * and the kernel gathers zf rows and adds the xyz half on the fly.  The (3+C)-channel grouped
+ * tensor of QueryAndGroup never exists and the first-layer GEMM shrinks from M*nsample to N columns.
+ * zf: (b,c,n) / (N,C) pre-projected features; wx: (c,3) row-major;
+ * rel_out (may be NULL): (b,3,npoints,nsample) / (3, M*nsample); y_out: (b,c,npoints,nsample) /
+ * (C, M*nsample) = the first layer's pre-BatchNorm output.  bwd scatters grad_y into the
+ * caller-zeroed grad_zf; d wx = grad_y . rel^T is a small GEMM left to the caller. */
+int mgar_query_group_proj_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz,
+                                    const float *new_xyz, const float *zf, const float *wx, const int *idx,
+                                    float *rel_out, float *y_out, void *stream);
+int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_y,
+                                    const int *idx, float *grad_zf, void *stream);
+int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                    const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf,
+                                    const float *wx, const int *idx, float *rel_out, float *y_out, void *stream);
+int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
+                                    const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf,
+                                    void *stream);
+
 /* ========== fused BatchNorm(train) + ReLU + max-over-nsample ========== */
 
 /* What follows the 1x1 convolution in every shared MLP of the SA / FP / RoI-pool modules:

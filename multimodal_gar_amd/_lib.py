@@ -44,6 +44,10 @@ _PROTOS = {
     "mgar_query_group_batch_bwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_query_group_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_query_group_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_proj_batch_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_proj_batch_bwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_query_group_proj_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_proj_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_bn_workspace_floats": [_I, _I, _I],
     "mgar_bn_train_stats": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],

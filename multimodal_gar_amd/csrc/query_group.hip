@@ -28,48 +28,62 @@ namespace mgar {
 // ------------------------------------------------------------------------------------------
 constexpr int QG_CCHUNK = 8;
 
-// grid: (ceil(cols/256), 1 + ceil(c/QG_CCHUNK), b); blockIdx.y == 0 writes the 3 xyz rows
+// grid: (ceil(cols/256), 1 + ceil(c/QG_CCHUNK), b); blockIdx.y == 0 writes the 3 xyz rows.
+// rel_out (may be NULL) and y_out are addressed with their own batch strides so that they can be
+// two tensors, or rows 0..2 / 3.. of one (b, 3+c, npoints, nsample) tensor.
+// wx (c, 3), optional: y[c] += wx[c] . rel  -- the xyz half of a first MLP layer whose feature
+// half was applied to the un-grouped features beforehand ("project, then group").
 __global__ __launch_bounds__(256) void qg_batch_fwd_kernel(int c, int n, int npoints, int nsample,
                                                            const float *__restrict__ xyz,
                                                            const float *__restrict__ new_xyz,
                                                            const float *__restrict__ features,
-                                                           const int *__restrict__ idx, float *__restrict__ out) {
+                                                           const float *__restrict__ wx,
+                                                           const int *__restrict__ idx, float *__restrict__ rel_out,
+                                                           size_t rel_bstride, float *__restrict__ y_out, size_t y_bstride) {
     const int cols = npoints * nsample;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= cols) return;
     const int bs = blockIdx.z;
     const int k = idx[(size_t)bs * cols + col];
-    float *dst = out + (size_t)bs * (3 + c) * cols + col;
-    if (blockIdx.y == 0) {
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (blockIdx.y == 0 || wx) {
         const int p = col / nsample;
         const float *q = new_xyz + ((size_t)bs * npoints + p) * 3;
         const float *s = xyz + ((size_t)bs * n + k) * 3;
-        dst[0] = s[0] - q[0];
-        dst[(size_t)cols] = s[1] - q[1];
-        dst[(size_t)2 * cols] = s[2] - q[2];
+        r0 = s[0] - q[0]; r1 = s[1] - q[1]; r2 = s[2] - q[2];
+    }
+    if (blockIdx.y == 0) {
+        if (rel_out) {
+            float *dst = rel_out + (size_t)bs * rel_bstride + col;
+            dst[0] = r0;
+            dst[(size_t)cols] = r1;
+            dst[(size_t)2 * cols] = r2;
+        }
         return;
     }
     const int c0 = (blockIdx.y - 1) * QG_CCHUNK;
     const int c1 = min(c0 + QG_CCHUNK, c);
     const float *src = features + ((size_t)bs * c + c0) * n + k;
-    dst += (size_t)(3 + c0) * cols;
+    float *dst = y_out + (size_t)bs * y_bstride + (size_t)c0 * cols + col;
 #pragma unroll 4
     for (int ci = c0; ci < c1; ++ci) {
-        *dst = *src;
+        float v = *src;
+        if (wx) v += wx[ci * 3 + 0] * r0 + wx[ci * 3 + 1] * r1 + wx[ci * 3 + 2] * r2;
+        *dst = v;
         src += n;
         dst += cols;
     }
 }
 
 // grid: (c, b); one workgroup owns one (b, c) row of grad_features, accumulated in LDS
-__global__ __launch_bounds__(1024) void qg_batch_bwd_lds_kernel(int c, int n, int cols, const float *__restrict__ grad_out,
-                                                                const int *__restrict__ idx,
+__global__ __launch_bounds__(1024) void qg_batch_bwd_lds_kernel(int c, int n, int cols, const float *__restrict__ grad_y,
+                                                                size_t y_bstride, const int *__restrict__ idx,
                                                                 float *__restrict__ grad_features) {
     extern __shared__ float row[];
     const int ci = blockIdx.x, bs = blockIdx.y;
     for (int i = threadIdx.x; i < n; i += blockDim.x) row[i] = 0.f;
     __syncthreads();
-    const float *g = grad_out + ((size_t)bs * (3 + c) + 3 + ci) * cols;
+    const float *g = grad_y + (size_t)bs * y_bstride + (size_t)ci * cols;
     const int *id = idx + (size_t)bs * cols;
     for (int e = threadIdx.x; e < cols; e += blockDim.x) atomicAdd(&row[id[e]], g[e]);
     __syncthreads();
@@ -80,14 +94,14 @@ __global__ __launch_bounds__(1024) void qg_batch_bwd_lds_kernel(int c, int n, in
     }
 }
 
-__global__ __launch_bounds__(256) void qg_batch_bwd_atomic_kernel(int c, int n, int cols, const float *__restrict__ grad_out,
-                                                                  const int *__restrict__ idx,
+__global__ __launch_bounds__(256) void qg_batch_bwd_atomic_kernel(int c, int n, int cols, const float *__restrict__ grad_y,
+                                                                  size_t y_bstride, const int *__restrict__ idx,
                                                                   float *__restrict__ grad_features) {
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= cols) return;
     const int ci = blockIdx.y, bs = blockIdx.z;
     atomicAdd(grad_features + ((size_t)bs * c + ci) * n + idx[(size_t)bs * cols + col],
-              grad_out[((size_t)bs * (3 + c) + 3 + ci) * cols + col]);
+              grad_y[(size_t)bs * y_bstride + (size_t)ci * cols + col]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -98,6 +112,7 @@ constexpr int QS_CH = 32;      // channels per LDS pass (one 128-byte piece per 
 
 struct QsTile {
     int src_row[QS_COLS];          // global feature row of each column, -1 = empty ball
+    float rel[QS_COLS][3];         // neighbour xyz relative to the query (0 for an empty ball)
     float tile[QS_COLS][QS_CH + 1];
 };
 
@@ -134,36 +149,48 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
                                                            const float *__restrict__ new_xyz,
                                                            const int *__restrict__ new_xyz_batch_cnt,
                                                            const float *__restrict__ features,
-                                                           const int *__restrict__ idx, float *__restrict__ out) {
+                                                           const float *__restrict__ wx, const int *__restrict__ idx,
+                                                           float *__restrict__ rel_out, float *__restrict__ y_out) {
     __shared__ QsTile t;
     int col0;
     const int ncol = qs_prologue(t, B, M, nsample, idx, new_xyz_batch_cnt, xyz_batch_cnt, col0);
     const size_t ms = (size_t)M * nsample;
-    // rows 0..2: neighbour xyz relative to the query, zero for an empty ball
+    // rows of rel_out: neighbour xyz relative to the query, zero for an empty ball
     for (int e = threadIdx.x; e < ncol * 3; e += 256) {
         const int r = e / ncol, cl = e - r * ncol;
         const int src = t.src_row[cl];
         const int m = (col0 + cl) / nsample;
-        out[(size_t)r * ms + col0 + cl] = src < 0 ? 0.f : xyz[(size_t)src * 3 + r] - new_xyz[(size_t)m * 3 + r];
+        const float v = src < 0 ? 0.f : xyz[(size_t)src * 3 + r] - new_xyz[(size_t)m * 3 + r];
+        t.rel[cl][r] = v;
+        if (rel_out) rel_out[(size_t)r * ms + col0 + cl] = v;
     }
-    // rows 3..: features, QS_CH channels per pass through the LDS tile
+    __syncthreads();
+    // rows of y_out: features (+ wx . rel), QS_CH channels per pass through the LDS tile
     for (int c0 = 0; c0 < C; c0 += QS_CH) {
         const int nch = min(QS_CH, C - c0);
         for (int e = threadIdx.x; e < ncol * QS_CH; e += 256) {      // lanes along c
             const int cl = e / QS_CH, ci = e - cl * QS_CH;
             const int src = t.src_row[cl];
-            t.tile[cl][ci] = (src >= 0 && ci < nch) ? features[(size_t)src * C + c0 + ci] : 0.f;
+            float v = 0.f;
+            if (src >= 0 && ci < nch) {
+                v = features[(size_t)src * C + c0 + ci];
+                if (wx) {
+                    const float *w = wx + (size_t)(c0 + ci) * 3;
+                    v += w[0] * t.rel[cl][0] + w[1] * t.rel[cl][1] + w[2] * t.rel[cl][2];
+                }
+            }
+            t.tile[cl][ci] = v;
         }
         __syncthreads();
         for (int e = threadIdx.x; e < nch * QS_COLS; e += 256) {     // lanes along the columns
             const int ci = e / QS_COLS, cl = e - ci * QS_COLS;
-            if (cl < ncol) out[(size_t)(3 + c0 + ci) * ms + col0 + cl] = t.tile[cl][ci];
+            if (cl < ncol) y_out[(size_t)(c0 + ci) * ms + col0 + cl] = t.tile[cl][ci];
         }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, int nsample, const float *__restrict__ grad_out,
+__global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, int nsample, const float *__restrict__ grad_y,
                                                            const int *__restrict__ idx,
                                                            const int *__restrict__ new_xyz_batch_cnt,
                                                            const int *__restrict__ xyz_batch_cnt,
@@ -176,7 +203,7 @@ __global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, 
         const int nch = min(QS_CH, C - c0);
         for (int e = threadIdx.x; e < nch * QS_COLS; e += 256) {     // coalesced reads of the gradient rows
             const int ci = e / QS_COLS, cl = e - ci * QS_COLS;
-            if (cl < ncol) t.tile[cl][ci] = grad_out[(size_t)(3 + c0 + ci) * ms + col0 + cl];
+            if (cl < ncol) t.tile[cl][ci] = grad_y[(size_t)(c0 + ci) * ms + col0 + cl];
         }
         __syncthreads();
         for (int e = threadIdx.x; e < ncol * QS_CH; e += 256) {      // lanes along c: contiguous atomic pieces
@@ -194,30 +221,29 @@ constexpr int QG_LDS_MAX_FLOATS = 36864;
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_query_group_batch_fwd(int b, int c, int n, int npoints,
-                                                                                int nsample, const float *xyz,
-                                                                                const float *new_xyz,
-                                                                                const float *features, const int *idx,
-                                                                                float *out, void *stream) {
-    MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group_batch_fwd: negative size");
-    MGAR_REQUIRE(b <= 65535, "query_group_batch_fwd: b > 65535");
+#define QG_API extern "C" __attribute__((visibility("default")))
+
+static int qg_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                        const float *features, const float *wx, const int *idx, float *rel_out, size_t rel_bstride,
+                        float *y_out, size_t y_bstride, void *stream, const char *what) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group (batch) fwd: negative size");
+    MGAR_REQUIRE(b <= 65535, "query_group (batch) fwd: b > 65535");
     if ((long long)b * npoints * nsample == 0) return MGAR_OK;
-    MGAR_REQUIRE(xyz && new_xyz && idx && out && (features || c == 0), "query_group_batch_fwd: null pointer");
+    MGAR_REQUIRE(xyz && new_xyz && idx && (features || c == 0) && (y_out || c == 0) && (rel_out || y_out),
+                 "query_group (batch) fwd: null pointer");
     dim3 grid(ceil_div((long long)npoints * nsample, 256), 1 + ceil_div(c, QG_CCHUNK), b);
     hipLaunchKernelGGL(qg_batch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, nsample, xyz, new_xyz,
-                       features, idx, out);
-    return check_launch("query_group_batch_fwd: launch failed");
+                       features, wx, idx, rel_out, rel_bstride, y_out, y_bstride);
+    return check_launch(what);
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_query_group_batch_bwd(int b, int c, int n, int npoints,
-                                                                                int nsample, const float *grad_out,
-                                                                                const int *idx, float *grad_features,
-                                                                                void *stream) {
-    MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group_batch_bwd: negative size");
-    MGAR_REQUIRE(b <= 65535 && c <= 65535, "query_group_batch_bwd: b or c > 65535");
+static int qg_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_y, size_t y_bstride, const int *idx,
+                        float *grad_features, void *stream, const char *what) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group (batch) bwd: negative size");
+    MGAR_REQUIRE(b <= 65535 && c <= 65535, "query_group (batch) bwd: b or c > 65535");
     const int cols = npoints * nsample;
     if ((long long)b * c * cols == 0) return MGAR_OK;
-    MGAR_REQUIRE(grad_out && idx && grad_features, "query_group_batch_bwd: null pointer");
+    MGAR_REQUIRE(grad_y && idx && grad_features, "query_group (batch) bwd: null pointer");
     if (n <= QG_LDS_MAX_FLOATS) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -226,40 +252,91 @@ extern "C" __attribute__((visibility("default"))) int mgar_query_group_batch_bwd
             attr_set = true;
         }
         hipLaunchKernelGGL(qg_batch_bwd_lds_kernel, dim3(c, b), dim3(cols >= 4096 ? 1024 : 256), (size_t)n * sizeof(float),
-                           (hipStream_t)stream, c, n, cols, grad_out, idx, grad_features);
+                           (hipStream_t)stream, c, n, cols, grad_y, y_bstride, idx, grad_features);
     } else {
         hipLaunchKernelGGL(qg_batch_bwd_atomic_kernel, dim3(ceil_div(cols, 256), c, b), dim3(256), 0, (hipStream_t)stream, c, n,
-                           cols, grad_out, idx, grad_features);
+                           cols, grad_y, y_bstride, idx, grad_features);
     }
-    return check_launch("query_group_batch_bwd: launch failed");
+    return check_launch(what);
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_query_group_stack_fwd(int B, int M, int C, int nsample,
-                                                                                const float *xyz, const int *xyz_batch_cnt,
-                                                                                const float *new_xyz,
-                                                                                const int *new_xyz_batch_cnt,
-                                                                                const float *features, const int *idx,
-                                                                                float *out, void *stream) {
-    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group_stack_fwd: negative size");
+QG_API int mgar_query_group_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                      const float *features, const int *idx, float *out, void *stream) {
+    const size_t cols = (size_t)npoints * nsample;
+    return qg_batch_fwd(b, c, n, npoints, nsample, xyz, new_xyz, features, nullptr, idx, out, (3 + c) * cols,
+                        out ? out + 3 * cols : nullptr, (3 + c) * cols, stream, "query_group_batch_fwd: launch failed");
+}
+
+QG_API int mgar_query_group_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
+                                      float *grad_features, void *stream) {
+    const size_t cols = (size_t)npoints * nsample;
+    return qg_batch_bwd(b, c, n, npoints, nsample, grad_out ? grad_out + 3 * cols : nullptr, (3 + c) * cols, idx, grad_features,
+                        stream, "query_group_batch_bwd: launch failed");
+}
+
+QG_API int mgar_query_group_proj_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz,
+                                           const float *new_xyz, const float *zf, const float *wx, const int *idx,
+                                           float *rel_out, float *y_out, void *stream) {
+    MGAR_REQUIRE(wx && zf && y_out, "query_group_proj_batch_fwd: null pointer");
+    const size_t cols = (size_t)npoints * nsample;
+    return qg_batch_fwd(b, c, n, npoints, nsample, xyz, new_xyz, zf, wx, idx, rel_out, 3 * cols, y_out, (size_t)c * cols, stream,
+                        "query_group_proj_batch_fwd: launch failed");
+}
+
+QG_API int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_y, const int *idx,
+                                           float *grad_zf, void *stream) {
+    return qg_batch_bwd(b, c, n, npoints, nsample, grad_y, (size_t)c * npoints * nsample, idx, grad_zf, stream,
+                        "query_group_proj_batch_bwd: launch failed");
+}
+
+static int qg_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt, const float *new_xyz,
+                        const int *new_xyz_batch_cnt, const float *features, const float *wx, const int *idx, float *rel_out,
+                        float *y_out, void *stream, const char *what) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group (stack) fwd: negative size");
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0) return MGAR_OK;
-    MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && out && (features || C == 0),
-                 "query_group_stack_fwd: null pointer");
+    MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && (features || C == 0) && (y_out || C == 0) &&
+                     (rel_out || y_out), "query_group (stack) fwd: null pointer");
     hipLaunchKernelGGL(qg_stack_fwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
-                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx, out);
-    return check_launch("query_group_stack_fwd: launch failed");
+                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, wx, idx, rel_out, y_out);
+    return check_launch(what);
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_query_group_stack_bwd(int B, int M, int C, int nsample,
-                                                                                const float *grad_out, const int *idx,
-                                                                                const int *new_xyz_batch_cnt,
-                                                                                const int *xyz_batch_cnt,
-                                                                                float *grad_features, void *stream) {
-    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group_stack_bwd: negative size");
+static int qg_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx, const int *new_xyz_batch_cnt,
+                        const int *xyz_batch_cnt, float *grad_features, void *stream, const char *what) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group (stack) bwd: negative size");
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0 || C == 0) return MGAR_OK;
-    MGAR_REQUIRE(grad_out && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group_stack_bwd: null pointer");
+    MGAR_REQUIRE(grad_y && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group (stack) bwd: null pointer");
     hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
-                       grad_out, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features);
-    return check_launch("query_group_stack_bwd: launch failed");
+                       grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features);
+    return check_launch(what);
+}
+
+QG_API int mgar_query_group_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                      const float *new_xyz, const int *new_xyz_batch_cnt, const float *features, const int *idx,
+                                      float *out, void *stream) {
+    const size_t ms = (size_t)M * nsample;
+    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, nullptr, idx, out,
+                        out ? out + 3 * ms : nullptr, stream, "query_group_stack_fwd: launch failed");
+}
+
+QG_API int mgar_query_group_stack_bwd(int B, int M, int C, int nsample, const float *grad_out, const int *idx,
+                                      const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_features, void *stream) {
+    return qg_stack_bwd(B, M, C, nsample, grad_out ? grad_out + 3 * (size_t)M * nsample : nullptr, idx, new_xyz_batch_cnt,
+                        xyz_batch_cnt, grad_features, stream, "query_group_stack_bwd: launch failed");
+}
+
+QG_API int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                           const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, const float *wx,
+                                           const int *idx, float *rel_out, float *y_out, void *stream) {
+    MGAR_REQUIRE(wx && zf && y_out, "query_group_proj_stack_fwd: null pointer");
+    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx, idx, rel_out, y_out, stream,
+                        "query_group_proj_stack_fwd: launch failed");
+}
+
+QG_API int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
+                                           const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf, void *stream) {
+    return qg_stack_bwd(B, M, C, nsample, grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, stream,
+                        "query_group_proj_stack_bwd: launch failed");
 }

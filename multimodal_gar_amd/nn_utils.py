@@ -38,10 +38,10 @@ class PointwiseSequential(nn.Sequential):
     csrc/bn_act.hip; ``forward_maxpool`` additionally folds the max over the last axis (nsample)
     into the last BatchNorm + ReLU so that activation is never written."""
 
-    def _run(self, x, pool_last):
+    def _run(self, x, pool_last, start=0):
         from . import bn_ops
         layers = list(self)
-        i, n = 0, len(layers)
+        i, n = start, len(layers)
         pooled = False
         while i < n:
             layer = layers[i]
@@ -70,7 +70,14 @@ class PointwiseSequential(nn.Sequential):
     def forward(self, x):
         return self._run(x, False)[0]
 
-    def forward_maxpool(self, x):
-        """(B, C, M, ns) -> (B, C', M): the MLP followed by a max over ns."""
-        y, pooled = self._run(x, True)
+    def forward_maxpool(self, x, start=0):
+        """(B, C, M, ns) -> (B, C', M): the MLP (from layer `start`) followed by a max over ns."""
+        y, pooled = self._run(x, True, start)
         return y if pooled else y.max(dim=3).values
+
+    def first_layer_foldable(self, c_in):
+        """True if folding the first layer into the grouping shrinks the gathered tensor: a bias-free
+        point-wise conv whose output is narrower than its (3 + C) input."""
+        conv = self[0] if len(self) else None
+        return conv is not None and _is_pointwise(conv) and conv.bias is None and conv.in_channels == c_in \
+            and conv.out_channels < c_in

@@ -73,3 +73,15 @@ def query_group_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_feat
     L.call("mgar_query_group_batch_bwd", b, c, n, npoints, nsample, L.fptr(grad_out), L.iptr(idx), L.fptr(grad_features),
            L.stream_of(grad_out))
     return 1
+
+
+def query_group_proj_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, zf, wx, idx, rel_out, y_out):
+    L.call("mgar_query_group_proj_batch_fwd", b, c, n, npoints, nsample, L.fptr(xyz), L.fptr(new_xyz), L.fptr(zf), L.fptr(wx),
+           L.iptr(idx), L.fptr(rel_out) if rel_out is not None else None, L.fptr(y_out), L.stream_of(xyz))
+    return 1
+
+
+def query_group_proj_grad_wrapper(b, c, n, npoints, nsample, grad_y, idx, grad_zf):
+    L.call("mgar_query_group_proj_batch_bwd", b, c, n, npoints, nsample, L.fptr(grad_y), L.iptr(idx), L.fptr(grad_zf),
+           L.stream_of(grad_y))
+    return 1

@@ -49,6 +49,13 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = pointnet2_utils.gather_operation(xyz_t, picked).transpose(1, 2).contiguous()
         per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            if (self.pool_method == 'max_pool' and features is not None and xyz.is_cuda
+                    and isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz
+                    and mlp.first_layer_foldable(3 + features.shape[1])):
+                # "project, then group": layer 0 is linear, apply its feature half to the N points first
+                y0 = grouper.forward_projected(xyz, new_xyz, features, mlp[0].weight)
+                per_scale.append(mlp.forward_maxpool(y0, start=1))
+                continue
             grouped = grouper(xyz, new_xyz, features)          # (B, C', npoint, nsample)
             if self.pool_method == 'max_pool':
                 per_scale.append(mlp.forward_maxpool(grouped))             # BN + ReLU + max fused on the device

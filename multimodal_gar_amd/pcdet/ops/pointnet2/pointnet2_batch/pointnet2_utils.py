@@ -209,6 +209,36 @@ class _FusedQueryGroup(Function):
         return None, None, grad_features, None
 
 
+class _FusedQueryGroupProj(Function):
+    """y = gather(zf) + wx . rel_xyz  (csrc/query_group.hip, "project, then group"): the output of
+    a first shared-MLP layer whose feature half (zf = W_f features) was applied before grouping."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, zf, wx, idx):
+        batch, n_pts, _ = xyz.size()
+        npoint, nsample = idx.size(1), idx.size(2)
+        chans = zf.size(1)
+        zf, wx = zf.contiguous(), wx.contiguous()
+        rel = _new(xyz, (batch, 3, npoint, nsample), torch.float32)
+        y = _new(xyz, (batch, chans, npoint, nsample), torch.float32)
+        pointnet2.query_group_proj_wrapper(batch, chans, n_pts, npoint, nsample, xyz, new_xyz, zf, wx, idx, rel, y)
+        ctx.save_for_backward(idx, rel)
+        ctx.dims = (chans, n_pts)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y):
+        idx, rel = ctx.saved_tensors
+        chans, n_pts = ctx.dims
+        batch, _, npoint, nsample = grad_y.size()
+        grad_y = grad_y.contiguous()
+        grad_zf = _new(grad_y, (batch, chans, n_pts), torch.float32, 0.0)
+        pointnet2.query_group_proj_grad_wrapper(batch, chans, n_pts, npoint, nsample, grad_y, idx, grad_zf)
+        grad_wx = torch.bmm(grad_y.flatten(2), rel.flatten(2).transpose(1, 2)).sum(dim=0)     # (C, 3)
+        return None, None, grad_zf, grad_wx, None
+
+
 class QueryAndGroup(nn.Module):
     """ball_query -> group xyz (made relative to the centre) -> group features -> concat.
     Output (B, 3 + C, npoint, nsample).  Reference: pointnet2_utils.py:231-264."""
@@ -224,6 +254,16 @@ class QueryAndGroup(nn.Module):
         if not self.use_xyz:
             return grouping_operation(features, idx)
         return _FusedQueryGroup.apply(xyz, new_xyz, features, idx)
+
+    def forward_projected(self, xyz, new_xyz, features, weight):
+        """First shared-MLP layer folded into the grouping: returns  W [rel_xyz ; grouped features]
+        (B, C_out, npoint, nsample) for a bias-free point-wise conv weight (C_out, 3 + C), without
+        ever building the (3 + C)-channel grouped tensor."""
+        assert self.use_xyz and features is not None
+        w = weight.view(weight.shape[0], -1)
+        zf = torch.bmm(w[:, 3:].unsqueeze(0).expand(features.shape[0], -1, -1), features)     # (B, C_out, N)
+        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        return _FusedQueryGroupProj.apply(xyz, new_xyz, zf, w[:, :3], idx)
 
 
 class GroupAll(nn.Module):

@@ -63,6 +63,13 @@ class StackSAModuleMSG(nn.Module):
         """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1]))."""
         per_scale = []
         for grouper, mlp in zip(self.groupers, self.mlps):
+            if (self.pool_method == 'max_pool' and features is not None and xyz.is_cuda and grouper.use_xyz
+                    and mlp.first_layer_foldable(3 + features.shape[1])):
+                # "project, then group": layer 0 is linear, apply its feature half to the N points first
+                y0, _ = grouper.forward_projected(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, mlp[0].weight)
+                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1)
+                per_scale.append(x.squeeze(0).permute(1, 0))
+                continue
             grouped, _ = grouper.forward_channel_major(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
             grouped = grouped.view(1, grouped.shape[0], new_xyz.shape[0], -1)              # (1, C, M, nsample)
             if self.pool_method == 'max_pool':

@@ -72,3 +72,16 @@ def query_group_grad_wrapper(B, M, C, nsample, grad_out, idx_raw, new_xyz_batch_
     L.call("mgar_query_group_stack_bwd", B, M, C, nsample, L.fptr(grad_out), L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt),
            L.iptr(xyz_batch_cnt), L.fptr(grad_features), L.stream_of(grad_out))
     return 1
+
+
+def query_group_proj_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx, idx_raw, rel_out, y_out):
+    L.call("mgar_query_group_proj_stack_fwd", B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
+           L.iptr(new_xyz_batch_cnt), L.fptr(zf), L.fptr(wx), L.iptr(idx_raw),
+           L.fptr(rel_out) if rel_out is not None else None, L.fptr(y_out), L.stream_of(xyz))
+    return 1
+
+
+def query_group_proj_grad_wrapper(B, M, C, nsample, grad_y, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf):
+    L.call("mgar_query_group_proj_stack_bwd", B, M, C, nsample, L.fptr(grad_y), L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt),
+           L.iptr(xyz_batch_cnt), L.fptr(grad_zf), L.stream_of(grad_y))
+    return 1

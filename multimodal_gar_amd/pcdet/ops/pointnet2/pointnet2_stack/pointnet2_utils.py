@@ -117,6 +117,40 @@ class _FusedQueryGroup(Function):
         return None, None, None, None, None, None, grad_features
 
 
+class _FusedQueryGroupProj(Function):
+    """ball query + y = gather(zf) + wx . rel_xyz, channel-major (C_out, M * nsample), zero columns for
+    empty balls ("project, then group", csrc/query_group.hip)."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx):
+        n_samples = xyz_batch_cnt.shape[0]
+        n_query = new_xyz.shape[0]
+        idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+        zf, wx = zf.contiguous(), wx.contiguous()
+        chans = zf.shape[1]
+        rel = _empty(xyz, (3, n_query * nsample), torch.float32)
+        y = _empty(xyz, (chans, n_query * nsample), torch.float32)
+        pointnet2.query_group_proj_wrapper(n_samples, n_query, chans, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+                                           zf, wx, idx, rel, y)
+        ctx.save_for_backward(idx, xyz_batch_cnt, new_xyz_batch_cnt, rel)
+        ctx.dims = (n_samples, n_query, chans, nsample, zf.shape[0])
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_y, grad_idx=None):
+        idx, xyz_batch_cnt, new_xyz_batch_cnt, rel = ctx.saved_tensors
+        n_samples, n_query, chans, nsample, n_rows = ctx.dims
+        grad_y = grad_y.contiguous()
+        grad_zf = torch.zeros((n_rows, chans), dtype=torch.float32, device=grad_y.device)
+        pointnet2.query_group_proj_grad_wrapper(n_samples, n_query, chans, nsample, grad_y, idx, new_xyz_batch_cnt,
+                                                xyz_batch_cnt, grad_zf)
+        grad_wx = grad_y @ rel.t()                                                            # (C, 3)
+        return None, None, None, None, None, None, grad_zf, grad_wx
+
+
 class QueryAndGroup(nn.Module):
     """Returns (new_features (M, 3 + C, nsample), idx).  Relative xyz and features of empty
     balls are zeroed.  Reference: pointnet2_utils.py:112-159."""
@@ -146,6 +180,16 @@ class QueryAndGroup(nn.Module):
         grouped, idx_raw = _FusedQueryGroup.apply(self.radius, self.nsample, xyz, xyz_batch_cnt.int(), new_xyz,
                                                   new_xyz_batch_cnt.int(), features)
         return (grouped if self.use_xyz else grouped[3:]), idx_raw
+
+    def forward_projected(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, weight):
+        """First shared-MLP layer folded into the grouping: W [rel_xyz ; grouped features] as a
+        channel-major (C_out, M * nsample) tensor for a bias-free point-wise conv weight
+        (C_out, 3 + C); the (3 + C)-channel grouped tensor is never built."""
+        assert self.use_xyz and features is not None
+        w = weight.view(weight.shape[0], -1)
+        zf = features @ w[:, 3:].t()                                                          # (N, C_out)
+        return _FusedQueryGroupProj.apply(self.radius, self.nsample, xyz, xyz_batch_cnt.int(), new_xyz,
+                                          new_xyz_batch_cnt.int(), zf, w[:, :3])
 
 
 class FarthestPointSampling(Function):
