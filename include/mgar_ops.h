@@ -211,6 +211,13 @@ int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsig
                             const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta,
                             float *dx, void *stream);
 
+/* Weight gradient of a point-wise convolution on the exact-fp32 MFMA:
+ *   dw[o][i] += sum_b sum_p dy[b,o,p] * x[b,i,p]      x (B,Cin,P), dy (B,Cout,P), dw (Cout,Cin)
+ * (backward-weights of the Conv2d 1x1 layers of the shared MLPs, pointnet2_batch/
+ * pointnet2_modules.py:86-92).  dw is ACCUMULATED into (caller zero-fills). */
+int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *dw,
+                           void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).

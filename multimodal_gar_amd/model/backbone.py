@@ -77,9 +77,18 @@ class Unit3D(nn.Module):
             x = F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
         else:
             x = self.conv3d(F.pad(x, _as_fpad(pads)))
+        relu_fused = False
         if self._use_batch_norm:
-            x = self.bn(x)
-        if self._activation_fn is not None:
+            y = None
+            if x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad and not self.bn.training):
+                # BatchNorm3d + ReLU in one streaming pass of csrc/bn_act.hip (the reference runs them
+                # as two kernels; I3D is frozen, so this is forward-only in MGAR-net)
+                from .. import bn_ops
+                relu_fused = self._activation_fn is F.relu
+                y = bn_ops.bn_act(x, self.bn, relu_fused)
+            x = self.bn(x) if y is None else y
+            relu_fused = relu_fused and y is not None
+        if self._activation_fn is not None and not relu_fused:
             x = self._activation_fn(x)
         return x
 

@@ -11,6 +11,34 @@ import torch
 import torch.nn as nn
 
 
+class _PointwiseConv(torch.autograd.Function):
+    """y = W x for x (B, Cin, P): forward and dX are library GEMMs; the weight gradient -- a GEMM with
+    a tiny (Cout x Cin) output and up to 15.7 M reduction columns -- runs on csrc/pointwise_dw.hip."""
+
+    @staticmethod
+    def forward(ctx, x3, w):
+        ctx.save_for_backward(x3, w)
+        return torch.bmm(w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib as L
+        x3, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.bmm(w.t().unsqueeze(0).expand(dy.shape[0], -1, -1), dy)
+        if ctx.needs_input_grad[1]:
+            x3c = x3.contiguous()
+            dw = torch.zeros_like(w)
+            L.call("mgar_pointwise_conv_dw", L.fptr(x3c), L.fptr(dy), x3c.shape[0], w.shape[1], w.shape[0], x3c.shape[2],
+                   L.fptr(dw), L.stream_of(dy))
+        return dx, dw
+
+
+_DW_MIN_COLUMNS = 1 << 16   # below this the library GEMM is fine
+
+
 def conv1x1(conv, x):
     """y[b, o, ...] = sum_i W[o, i] x[b, i, ...] (+ bias) for a kernel-size-1 ConvNd."""
     w = conv.weight.view(1, conv.out_channels, conv.in_channels)
@@ -18,7 +46,11 @@ def conv1x1(conv, x):
     # 3-D @ 3-D: the result is produced directly as (B, C_out, P).  (A 2-D weight makes torch fold
     # the batch into the GEMM's rows and hand back a TRANSPOSED view, which the next op then
     # materialises with a slow strided copy of the whole activation.)
-    y = torch.bmm(w.expand(x3.shape[0], -1, -1), x3)
+    if (x3.is_cuda and x3.dtype == torch.float32 and x3.shape[0] * x3.shape[2] >= _DW_MIN_COLUMNS
+            and conv.out_channels <= 256 and torch.is_grad_enabled() and conv.weight.requires_grad):
+        y = _PointwiseConv.apply(x3, w[0].contiguous())
+    else:
+        y = torch.bmm(w.expand(x3.shape[0], -1, -1), x3)
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1)
     return y.view(x.shape[0], conv.out_channels, *x.shape[2:])
