@@ -218,6 +218,12 @@ int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsig
 int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *dw,
                            void *stream);
 
+/* MaxPool3dSamePadding.forward of the reference's I3D (model/backbone.py:99-131): zero "same"
+ * padding + max pooling without materialising the padded tensor.  x (NC, T, H, W) -> y (NC, ceil(T/st),
+ * ceil(H/sh), ceil(W/sw)).  Forward only (I3D is frozen in MGAR-net). */
+int mgar_maxpool3d_same_fwd(const float *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh,
+                            int sw, float *y, void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).

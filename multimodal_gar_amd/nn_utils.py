@@ -39,6 +39,16 @@ class _PointwiseConv(torch.autograd.Function):
 _DW_MIN_COLUMNS = 1 << 16   # below this the library GEMM is fine
 
 
+def pointwise_dw(x3, dy):
+    """sum_b dy[b] @ x3[b]^T -> (Cout, Cin) on csrc/pointwise_dw.hip (x3 (B, Cin, P), dy (B, Cout, P))."""
+    from . import _lib as L
+    x3, dy = x3.contiguous(), dy.contiguous()
+    dw = torch.zeros((dy.shape[1], x3.shape[1]), dtype=torch.float32, device=dy.device)
+    L.call("mgar_pointwise_conv_dw", L.fptr(x3), L.fptr(dy), x3.shape[0], x3.shape[1], dy.shape[1], x3.shape[2], L.fptr(dw),
+           L.stream_of(dy))
+    return dw
+
+
 def conv1x1(conv, x):
     """y[b, o, ...] = sum_i W[o, i] x[b, i, ...] (+ bias) for a kernel-size-1 ConvNd."""
     w = conv.weight.view(1, conv.out_channels, conv.in_channels)
@@ -47,7 +57,8 @@ def conv1x1(conv, x):
     # the batch into the GEMM's rows and hand back a TRANSPOSED view, which the next op then
     # materialises with a slow strided copy of the whole activation.)
     if (x3.is_cuda and x3.dtype == torch.float32 and x3.shape[0] * x3.shape[2] >= _DW_MIN_COLUMNS
-            and conv.out_channels <= 256 and torch.is_grad_enabled() and conv.weight.requires_grad):
+            and conv.out_channels <= 64 and conv.in_channels <= 64    # skinny output: where the library GEMM is 4-8x off
+            and torch.is_grad_enabled() and conv.weight.requires_grad):
         y = _PointwiseConv.apply(x3, w[0].contiguous())
     else:
         y = torch.bmm(w.expand(x3.shape[0], -1, -1), x3)

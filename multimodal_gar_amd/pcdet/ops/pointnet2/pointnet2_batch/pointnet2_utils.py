@@ -235,7 +235,8 @@ class _FusedQueryGroupProj(Function):
         grad_y = grad_y.contiguous()
         grad_zf = _new(grad_y, (batch, chans, n_pts), torch.float32, 0.0)
         pointnet2.query_group_proj_grad_wrapper(batch, chans, n_pts, npoint, nsample, grad_y, idx, grad_zf)
-        grad_wx = torch.bmm(grad_y.flatten(2), rel.flatten(2).transpose(1, 2)).sum(dim=0)     # (C, 3)
+        from .....nn_utils import pointwise_dw
+        grad_wx = pointwise_dw(rel.flatten(2), grad_y.flatten(2))                              # (C, 3)
         return None, None, grad_zf, grad_wx, None
 
 

@@ -147,7 +147,8 @@ class _FusedQueryGroupProj(Function):
         grad_zf = torch.zeros((n_rows, chans), dtype=torch.float32, device=grad_y.device)
         pointnet2.query_group_proj_grad_wrapper(n_samples, n_query, chans, nsample, grad_y, idx, new_xyz_batch_cnt,
                                                 xyz_batch_cnt, grad_zf)
-        grad_wx = grad_y @ rel.t()                                                            # (C, 3)
+        from .....nn_utils import pointwise_dw
+        grad_wx = pointwise_dw(rel.unsqueeze(0), grad_y.unsqueeze(0))                          # (C, 3)
         return None, None, None, None, None, None, grad_zf, grad_wx
 
 

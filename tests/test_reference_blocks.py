@@ -133,3 +133,32 @@ def test_gar_fusion_net3_routes_agree_in_gradients():
         grads.append((r.grad, l.grad, net.AttFusModule1.WQ_r.grad, net.D_embed[0].weight.grad, net.card_net[0].weight.grad))
     for a, b in zip(*grads):
         close(a, b.cpu().numpy(), rtol=5e-4, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_i3d_on_device_matches_reference_golden():
+    """Device path of I3D: fused BN3d + ReLU (bn_act.hip) and fused same-padding max pool
+    (maxpool3d.hip) against the reference's own output."""
+    from multimodal_gar_amd.model.backbone import InceptionI3d
+    m = InceptionI3d(final_endpoint='Mixed_4f'); m.build()
+    fill_deterministic(m, seed=2).eval()
+    m = m.cuda()
+    with torch.no_grad():
+        y = m.extract_features(torch.from_numpy(G["i3d_x"]).cuda())
+    close(y, G["i3d_y"], rtol=2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,k,s", [((2, 5, 15, 33, 47), (3, 3, 3), (2, 2, 2)), ((1, 7, 8, 20, 31), (1, 3, 3), (1, 2, 2)),
+                                       ((2, 3, 4, 9, 10), (3, 3, 3), (1, 1, 1)), ((1, 2, 5, 6, 7), (2, 2, 2), (2, 2, 2))])
+def test_maxpool3d_same_padding_kernel(shape, k, s):
+    from multimodal_gar_amd.model.backbone import MaxPool3dSamePadding
+    torch.manual_seed(0)
+    x = torch.randn(shape) - 0.5            # mostly negative: the zero padding must win where it is touched
+    pool = MaxPool3dSamePadding(kernel_size=list(k), stride=s, padding=0)
+    want = pool(x)                          # CPU: F.pad + MaxPool3d, the reference's op chain
+    got = pool(x.cuda())
+    assert got.shape == want.shape
+    assert torch.equal(got.cpu(), want)
+    m = torch.nn.Sequential()
+    # train-mode I3D on the device vs CPU torch (batch statistics through bn_act.hip)
