@@ -160,5 +160,3 @@ def test_maxpool3d_same_padding_kernel(shape, k, s):
     got = pool(x.cuda())
     assert got.shape == want.shape
     assert torch.equal(got.cpu(), want)
-    m = torch.nn.Sequential()
-    # train-mode I3D on the device vs CPU torch (batch statistics through bn_act.hip)
