@@ -84,6 +84,14 @@ int mgar_three_interpolate_batch(int b, int c, int m, int n, const float *points
 int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                       const float *weight, float *grad_points, void *stream);
 
+/* three_interpolate backward through an inverted index (no atomics): for every known point j of
+ * cloud b, entries ptr[b*m + j] .. ptr[b*m + j + 1] of list_u / list_w are the unknown points that
+ * reference it and their weights (built by the caller from idx / weight: a stable sort by b*m + idx).
+ * grad_points (b,c,m) is accumulated into.  Same result as mgar_three_interpolate_grad_batch. */
+int mgar_three_interpolate_grad_csr_batch(int b, int c, int n, int m, const float *grad_out, const int *ptr,
+                                          const int *list_u, const float *list_w, float *grad_points,
+                                          void *stream);
+
 /* ============== pointnet2_stack: (N1+N2+..., 3|C) + per-sample counts ================= */
 
 /* ball_query_wrapper   pcdet/ops/pointnet2/pointnet2_stack/src/pointnet2_api.cpp:13

@@ -130,7 +130,55 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
 }
 
 // ---- apply + max over nsample: 4 B read per element, 5 B written per GROUP ---------------------
-// x (rows = B*C, M, NS) -> out (rows, M), arg (rows, M) uint8.  grid (ceil(M/256), rows)
+// x (rows = B*C, M, NS) -> out (rows, M), arg (rows, M) uint8 (first arg-max).
+// Lanes run along the flat (m, s) index, one float4 per lane (fully coalesced 16-byte reads); the
+// NS/4 lanes that share a group combine their (value, index) pairs with an xor butterfly on the DPP
+// crossbar (quad_perm, row_half_mirror, row_mirror).  grid (rows, ceil(M*NS/4 / 256))
+__device__ __forceinline__ void max_pair(float &v, int &i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+template <int CTRL>
+__device__ __forceinline__ void dpp_max_step(float &v, int &i) {
+    const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+    const int oi = __builtin_amdgcn_update_dpp(0, i, CTRL, 0xF, 0xF, false);
+    max_pair(v, i, ov, oi);
+}
+
+template <bool RELU, int G>   // G = NS / 4 lanes per group: 1, 2, 4, 8 or 16
+__global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__restrict__ x, int C, int M, int NS,
+                                                                const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                float *__restrict__ out, unsigned char *__restrict__ arg) {
+    const int row = blockIdx.x;
+    const int c = row % C;
+    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const long long q = (long long)blockIdx.y * BN_THREADS + threadIdx.x;   // float4 index inside the row
+    const long long nq = (long long)M * G;
+    const bool live = q < nq;                                                // whole groups are live or dead together
+    float best = -__builtin_inff();
+    int bi = 0;
+    if (live) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)row * M * NS + q * 4);
+        const int s0 = (int)(q % G) * 4;
+        const float a[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (a[u] > best) { best = a[u]; bi = s0 + u; }
+    }
+    if (G >= 2) dpp_max_step<0xB1>(best, bi);    // quad_perm [1,0,3,2]  (xor 1)
+    if (G >= 4) dpp_max_step<0x4E>(best, bi);    // quad_perm [2,3,0,1]  (xor 2)
+    if (G >= 8) dpp_max_step<0x141>(best, bi);   // row_half_mirror      (acts as xor 4 once quads agree)
+    if (G >= 16) dpp_max_step<0x140>(best, bi);  // row_mirror           (acts as xor 8)
+    if (live && (threadIdx.x & (G - 1)) == 0) {
+        const long long m = q / G;
+        out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
+        arg[(size_t)row * M + m] = (unsigned char)bi;
+    }
+}
+
+// generic fallback (NS not in {4, 8, 16, 32, 64}): one thread per group.  grid (rows, ceil(M/256))
 template <bool RELU>
 __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restrict__ x, int C, int M, int NS,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -145,19 +193,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restr
     const float *xr = x + ((size_t)row * M + m) * NS;
     float best = -__builtin_inff();
     int bi = 0;
-    if ((NS & 3) == 0) {
-        for (int s = 0; s < NS; s += 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(xr + s);
-            const float a[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (a[u] > best) { best = a[u]; bi = s + u; }
-        }
-    } else {
-        for (int s = 0; s < NS; ++s) {
-            const float a = xr[s] * sc + sh;
-            if (a > best) { best = a; bi = s; }
-        }
+    for (int s = 0; s < NS; ++s) {
+        const float a = xr[s] * sc + sh;
+        if (a > best) { best = a; bi = s; }
     }
     out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
     arg[(size_t)row * M + m] = (unsigned char)bi;
@@ -377,10 +415,24 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(x && out && arg && mean && invstd, "bn_act_maxpool_fwd: null pointer");
     MGAR_REQUIRE((long long)M <= 65535LL * BN_THREADS, "bn_act_maxpool_fwd: M too large");
-    dim3 grid(B * C, ceil_div(M, BN_THREADS));
     hipStream_t st = (hipStream_t)stream;
-    if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
-    else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
+#define BN_MAX_VEC(G)                                                                                                  \
+    {                                                                                                                  \
+        dim3 gv(B * C, ceil_div((long long)M * (G), BN_THREADS));                                                      \
+        if (relu) hipLaunchKernelGGL((bn_max_vec_kernel<true, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg); \
+        else hipLaunchKernelGGL((bn_max_vec_kernel<false, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);     \
+    }
+    if (nsample == 4) BN_MAX_VEC(1)
+    else if (nsample == 8) BN_MAX_VEC(2)
+    else if (nsample == 16) BN_MAX_VEC(4)
+    else if (nsample == 32) BN_MAX_VEC(8)
+    else if (nsample == 64) BN_MAX_VEC(16)
+    else {
+        dim3 grid(B * C, ceil_div(M, BN_THREADS));
+        if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
+        else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
+    }
+#undef BN_MAX_VEC
     return check_launch("bn_act_maxpool_fwd: launch failed");
 }
 

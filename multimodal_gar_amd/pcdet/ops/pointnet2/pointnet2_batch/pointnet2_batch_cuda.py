@@ -85,3 +85,9 @@ def query_group_proj_grad_wrapper(b, c, n, npoints, nsample, grad_y, idx, grad_z
     L.call("mgar_query_group_proj_batch_bwd", b, c, n, npoints, nsample, L.fptr(grad_y), L.iptr(idx), L.fptr(grad_zf),
            L.stream_of(grad_y))
     return 1
+
+
+def three_interpolate_grad_csr_wrapper(b, c, n, m, grad_out, ptr, list_u, list_w, grad_points):
+    L.call("mgar_three_interpolate_grad_csr_batch", b, c, n, m, L.fptr(grad_out), L.iptr(ptr), L.iptr(list_u), L.fptr(list_w),
+           L.fptr(grad_points), L.stream_of(grad_out))
+    return 1

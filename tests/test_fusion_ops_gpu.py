@@ -188,7 +188,8 @@ def test_bn_act_matches_torch(shape, relu):
     close(ye, yre)
 
 
-@pytest.mark.parametrize("shape", [(3, 16, 700, 16), (1, 32, 4096, 16), (5, 8, 77, 32), (2, 4, 10, 5)])
+@pytest.mark.parametrize("shape", [(3, 16, 700, 16), (1, 32, 4096, 16), (5, 8, 77, 32), (2, 4, 10, 5), (2, 6, 333, 8),
+                                   (3, 5, 129, 64), (2, 3, 50, 4)])
 def test_bn_act_maxpool_matches_torch(shape):
     from multimodal_gar_amd import bn_ops
     torch.manual_seed(shape[2])

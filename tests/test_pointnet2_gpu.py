@@ -211,6 +211,25 @@ def test_three_interpolate_batch_and_stack(ops, oracle):
     np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad_stack(g, idx[0], w[0], m), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("b,c,m,n", [(3, 40, 64, 5000), (2, 5, 300, 900), (1, 16, 1, 77), (2, 33, 4096, 16384)])
+def test_three_interpolate_batch_grad_paths(ops, oracle, b, c, m, n):
+    """c >= 16 takes the inverted-index backward (no atomics), c < 16 the LDS-atomic one; the forward
+    stages the known rows in LDS.  Some known points are referenced by nobody, some by many."""
+    pb = ops[0]
+    rng = np.random.default_rng(b * 1000 + c)
+    feats = rng.standard_normal((b, c, m)).astype(np.float32)
+    idx = rng.integers(0, max(1, m // 2), (b, n, 3)).astype(np.int32)
+    w = rng.uniform(0, 1, (b, n, 3)).astype(np.float32)
+    f = dev(feats).requires_grad_(True)
+    out = pb.three_interpolate(f, dev(idx), dev(w))
+    np.testing.assert_array_equal(out.detach().cpu().numpy(), oracle.three_interpolate_batch(feats, idx, w))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    out.backward(dev(g))
+    want = oracle.three_interpolate_grad_batch(g, idx, w, m)
+    scale = np.abs(want).max() + 1.0
+    np.testing.assert_allclose(f.grad.cpu().numpy(), want, rtol=1e-5, atol=1e-5 * scale)
+
+
 # --------------------------------------------------------------------- voxel query
 @pytest.mark.parametrize("rng_zyx,radius,ns", [((2, 2, 2), 1.0, 8), ((4, 4, 4), 1.6, 16), ((1, 3, 9), 2.0, 4)])
 def test_voxel_query(ops, oracle, rng_zyx, radius, ns):
