@@ -84,13 +84,16 @@ int mgar_three_interpolate_batch(int b, int c, int m, int n, const float *points
 int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                       const float *weight, float *grad_points, void *stream);
 
-/* three_interpolate backward through an inverted index (no atomics): for every known point j of
- * cloud b, entries ptr[b*m + j] .. ptr[b*m + j + 1] of list_u / list_w are the unknown points that
- * reference it and their weights (built by the caller from idx / weight: a stable sort by b*m + idx).
- * grad_points (b,c,m) is accumulated into.  Same result as mgar_three_interpolate_grad_batch. */
-int mgar_three_interpolate_grad_csr_batch(int b, int c, int n, int m, const float *grad_out, const int *ptr,
-                                          const int *list_u, const float *list_w, float *grad_points,
-                                          void *stream);
+/* three_interpolate backward through an inverted index (no atomics).  `list` holds, cloud after
+ * cloud, the 3n (known point j, unknown point u, weight) entries of that cloud sorted by j with a
+ * STABLE sort (so ascending (u, k) inside one j; this fixes the summation order), 2 ints per entry:
+ * list[2e] = (j << 16) | u, list[2e+1] = bit pattern of the fp32 weight.  Needs n <= 36864 and
+ * m <= 65535 (MGAR_EUNSUPPORTED otherwise: use mgar_three_interpolate_grad_batch).  grad_points
+ * (b,c,m) must be ZEROED by the caller: known points with entries are overwritten, the others are
+ * left alone.  Same result as mgar_three_interpolate_grad_batch on a zeroed buffer up to fp32
+ * summation order. */
+int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m, const float *grad_out, const int *list,
+                                             float *grad_points, void *stream);
 
 /* ============== pointnet2_stack: (N1+N2+..., 3|C) + per-sample counts ================= */
 

@@ -32,7 +32,7 @@ _PROTOS = {
     "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
-    "mgar_three_interpolate_grad_csr_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_three_interpolate_grad_sorted_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_ball_query_stack": [_I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_query_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_fps_stack": [_I, _I, _P, _P, _P, _P, _P, _P],

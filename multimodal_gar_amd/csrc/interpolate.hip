@@ -137,39 +137,145 @@ __global__ __launch_bounds__(1024) void three_interp_batch_fwd_lds_kernel(int c,
     }
 }
 
-// Backward through an inverted index (CSR by known point): lists[ptr[b*m + j] .. ptr[b*m + j + 1]) hold
-// the (unknown point u, weight w) pairs that reference known point j.  A workgroup stages CH rows of
-// grad_out (CH * n floats) in LDS and every known point sums its list from LDS -- no atomics (LDS float
-// atomics run at ~0.3 lanes/clk/CU here: 8.2 ms for the level-1 FP module at config c3).
-// grid (ceil(c/CH), b)
-__global__ __launch_bounds__(1024) void three_interp_batch_bwd_csr_kernel(int c, int n, int m, int CH,
-                                                                          const float *__restrict__ grad_out,
-                                                                          const int *__restrict__ ptr,
-                                                                          const int *__restrict__ list_u,
-                                                                          const float *__restrict__ list_w,
-                                                                          float *__restrict__ grad_points) {
+// Backward through an inverted index: `list` holds, per cloud, its 3n (known point j, unknown point
+// u, weight) entries sorted by j (stable, so ascending (u, k) inside one j), packed as
+// int2{(j << 16) | u, weight bits}.  A workgroup stages CH rows of grad_out (CH * n floats) in LDS;
+// its waves walk contiguous runs of the sorted entries 64 at a time (coalesced), gather from LDS and
+// reduce runs of equal j with a segmented wave scan, so every known point is written exactly once --
+// no atomics (LDS float atomics run at ~0.3 lanes/clk/CU here: 8.2 ms for the level-1 FP module of
+// config c3) and no per-point list walk (list lengths are very skewed: FPS puts few known points into
+// dense clusters, so some lists hold hundreds of entries).  Segments that cross a wave boundary
+// go through 2 records per wave in LDS and are merged in wave order by one thread per channel, so the
+// summation order -- and with it the result -- is fixed.  Known points nobody references are not
+// written: the caller hands in a zeroed grad_points.  grid (ceil(c/CH), b)
+// one step of the segmented scan: fetch (key, v) from the DPP source lane, add where the keys agree
+template <int CH, int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_step(int key, float (&v)[CH], bool has_src) {
+    const int ku = __builtin_amdgcn_update_dpp(-1, key, CTRL, ROW_MASK, 0xF, false);
+    const bool take = has_src && ku == key;
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) {
+        const float vu = dpp_get<CTRL, ROW_MASK>(0.f, v[ch]);
+        if (take) v[ch] = vu + v[ch];
+    }
+}
+
+template <int CH>
+__global__ __launch_bounds__(1024) void three_interp_batch_bwd_sorted_kernel(int c, int n, int m,
+                                                                             const float *__restrict__ grad_out,
+                                                                             const int2 *__restrict__ list,
+                                                                             float *__restrict__ grad_points) {
     extern __shared__ float rows[];  // [CH][n]
+    __shared__ int rec_key[32];
+    __shared__ float rec_sum[32][CH];
     const int c0 = blockIdx.x * CH, bs = blockIdx.y;
     const int nch = min(CH, c - c0);
     const float *src = grad_out + ((size_t)bs * c + c0) * n;
-    for (int i = threadIdx.x; i < nch * n; i += blockDim.x) rows[i] = src[i];
+    if ((n & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < nch * n; i += blockDim.x * 4)
+            *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
+    } else {
+        for (int i = threadIdx.x; i < nch * n; i += blockDim.x) rows[i] = src[i];
+    }
+    if (threadIdx.x < 32) rec_key[threadIdx.x] = -1;
     __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int E = 3 * n, chunks = (E + 63) >> 6, cpw = (chunks + nwaves - 1) / nwaves;
+    const int2 *L = list + (size_t)bs * E;
     float *dst = grad_points + ((size_t)bs * c + c0) * m;
-    for (int j = threadIdx.x; j < m; j += blockDim.x) {
-        const int e0 = ptr[(size_t)bs * m + j], e1 = ptr[(size_t)bs * m + j + 1];
-        float acc[8];
+
+    // one lane delivers a finished (key, sums): the wave's first delivery goes to its head record
+    auto deliver = [&](int key, const float (&sum)[CH], bool to_head) {
+        if (key >= m) return;  // padding lanes behind the last entry
+        if (to_head) {
+            rec_key[2 * wave] = key;
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch) acc[ch] = 0.f;
-        for (int e = e0; e < e1; ++e) {
-            const int u = list_u[e];
-            const float w = list_w[e];
+            for (int ch = 0; ch < CH; ++ch) rec_sum[2 * wave][ch] = sum[ch];
+        } else {
 #pragma unroll
-            for (int ch = 0; ch < 8; ++ch)
-                if (ch < nch) acc[ch] += rows[(size_t)ch * n + u] * w;
+            for (int ch = 0; ch < CH; ++ch)
+                if (ch < nch) dst[(size_t)ch * m + key] = sum[ch];
+        }
+    };
+
+    int carry_key = -1;  // wave-uniform: the segment still open at the end of the previous chunk
+    float carry[CH];
+#pragma unroll
+    for (int ch = 0; ch < CH; ++ch) carry[ch] = 0.f;
+    bool first_pending = true;
+    const int q1 = min((wave + 1) * cpw, chunks);
+    constexpr int PF = 4;  // chunks fetched per round trip: the walk is latency-bound otherwise
+    for (int qb = wave * cpw; qb < q1; qb += PF) {
+        int2 pf[PF];
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int e = (qb + k) * 64 + lane;
+            pf[k] = (qb + k < q1 && e < E) ? L[e] : make_int2(m << 16, 0);
         }
 #pragma unroll
-        for (int ch = 0; ch < 8; ++ch)
-            if (ch < nch) dst[(size_t)ch * m + j] += acc[ch];
+        for (int k = 0; k < PF; ++k) {
+            if (qb + k >= q1) break;
+            const int2 en = pf[k];
+            const int key = (int)((unsigned)en.x >> 16);
+            const int u = en.x & 0xffff;
+            const float w = __int_as_float(en.y);
+            float v[CH];
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) v[ch] = (ch < nch && key < m) ? rows[(size_t)ch * n + u] * w : 0.f;
+            // segmented inclusive scan on DPP (keys are sorted: an equal key d lanes back => same segment):
+            // row_shr 1/2/4/8 inside rows of 16, then lane 15 / lane 31 broadcasts across rows
+            seg_scan_step<CH, 0x111, 0xF>(key, v, (lane & 15) >= 1);
+            seg_scan_step<CH, 0x112, 0xF>(key, v, (lane & 15) >= 2);
+            seg_scan_step<CH, 0x114, 0xF>(key, v, (lane & 15) >= 4);
+            seg_scan_step<CH, 0x118, 0xF>(key, v, (lane & 15) >= 8);
+            seg_scan_step<CH, 0x142, 0xA>(key, v, (lane & 16) != 0);
+            seg_scan_step<CH, 0x143, 0xC>(key, v, lane >= 32);
+            const int key_next = __shfl_down(key, 1);
+            const bool is_tail = lane < 63 && key_next != key;
+            const int key0 = __builtin_amdgcn_readfirstlane(key);
+            if (carry_key >= 0 && key0 != carry_key) {  // the open segment ended exactly at the chunk border
+                if (lane == 0) deliver(carry_key, carry, first_pending);
+                first_pending = false;
+                carry_key = -1;
+            }
+            if (carry_key >= 0 && key == carry_key && (is_tail || lane == 63)) {
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) v[ch] = carry[ch] + v[ch];
+            }
+            const unsigned long long tails = __ballot(is_tail);
+            if (tails) {
+                const int head_lane = first_pending ? (int)__builtin_ctzll(tails) : -1;
+                if (is_tail) deliver(key, v, lane == head_lane);
+                first_pending = false;
+            }
+            carry_key = __builtin_amdgcn_readlane(key, 63);
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) carry[ch] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[ch]), 63));
+        }
+    }
+    if (carry_key >= 0 && carry_key < m && lane == 0) {
+        rec_key[2 * wave + 1] = carry_key;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch) rec_sum[2 * wave + 1][ch] = carry[ch];
+    }
+    __syncthreads();
+    if (threadIdx.x < nch) {  // merge the wave-border records in wave order
+        const int ch = threadIdx.x;
+        int cur = -1;
+        float sum = 0.f;
+        for (int r = 0; r < 2 * nwaves; ++r) {
+            const int k = rec_key[r];
+            if (k < 0) continue;
+            if (k == cur) {
+                sum = sum + rec_sum[r][ch];
+            } else {
+                if (cur >= 0) dst[(size_t)ch * m + cur] = sum;
+                cur = k;
+                sum = rec_sum[r][ch];
+            }
+        }
+        if (cur >= 0) dst[(size_t)ch * m + cur] = sum;
     }
 }
 
@@ -386,29 +492,38 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
     return check_launch("three_interpolate_grad_stack: launch failed");
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_csr_batch(int b, int c, int n, int m,
-                                                                                            const float *grad_out,
-                                                                                            const int *ptr, const int *list_u,
-                                                                                            const float *list_w,
-                                                                                            float *grad_points, void *stream) {
-    MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad_csr_batch: negative size");
-    MGAR_REQUIRE(b <= 65535, "three_interpolate_grad_csr_batch: b > 65535");
-    if ((long long)b * c * n == 0 || m == 0) return MGAR_OK;
-    MGAR_REQUIRE(grad_out && ptr && list_u && list_w && grad_points, "three_interpolate_grad_csr_batch: null pointer");
-    if (n > TI_LDS_MAX_FLOATS) {
-        set_error("three_interpolate_grad_csr_batch: n too large for the LDS row");
-        return MGAR_EUNSUPPORTED;
-    }
+template <int CH>
+static void launch_bwd_sorted(int b, int c, int n, int m, const float *grad_out, const int *list, float *grad_points,
+                              hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)three_interp_batch_bwd_csr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  TI_LDS_MAX_FLOATS * (int)sizeof(float));
+        (void)hipFuncSetAttribute((const void *)mgar::three_interp_batch_bwd_sorted_kernel<CH>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, mgar::TI_LDS_MAX_FLOATS * (int)sizeof(float));
         attr_set = true;
     }
+    hipLaunchKernelGGL((mgar::three_interp_batch_bwd_sorted_kernel<CH>), dim3(ceil_div(c, CH), b), dim3(n >= 1024 ? 1024 : 256),
+                       (size_t)CH * n * sizeof(float), st, c, n, m, grad_out, reinterpret_cast<const int2 *>(list), grad_points);
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m,
+                                                                                               const float *grad_out,
+                                                                                               const int *list,
+                                                                                               float *grad_points, void *stream) {
+    MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad_sorted_batch: negative size");
+    MGAR_REQUIRE(b <= 65535, "three_interpolate_grad_sorted_batch: b > 65535");
+    if ((long long)b * c * n == 0 || m == 0) return MGAR_OK;
+    MGAR_REQUIRE(grad_out && list && grad_points, "three_interpolate_grad_sorted_batch: null pointer");
+    if (n > TI_LDS_MAX_FLOATS || m > 65535) {
+        set_error("three_interpolate_grad_sorted_batch: needs n <= 36864 (LDS row) and m <= 65535 (packed entry)");
+        return MGAR_EUNSUPPORTED;
+    }
     int ch = TI_LDS_MAX_FLOATS / n;
-    ch = ch > 8 ? 8 : ch;
+    ch = ch >= 8 ? 8 : (ch >= 4 ? 4 : (ch >= 2 ? 2 : 1));
     while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
-    hipLaunchKernelGGL(three_interp_batch_bwd_csr_kernel, dim3(ceil_div(c, ch), b), dim3(m >= 4096 ? 1024 : 256),
-                       (size_t)ch * n * sizeof(float), (hipStream_t)stream, c, n, m, ch, grad_out, ptr, list_u, list_w, grad_points);
-    return check_launch("three_interpolate_grad_csr_batch: launch failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (ch == 8) launch_bwd_sorted<8>(b, c, n, m, grad_out, list, grad_points, st);
+    else if (ch == 4) launch_bwd_sorted<4>(b, c, n, m, grad_out, list, grad_points, st);
+    else if (ch == 2) launch_bwd_sorted<2>(b, c, n, m, grad_out, list, grad_points, st);
+    else launch_bwd_sorted<1>(b, c, n, m, grad_out, list, grad_points, st);
+    return check_launch("three_interpolate_grad_sorted_batch: launch failed");
 }

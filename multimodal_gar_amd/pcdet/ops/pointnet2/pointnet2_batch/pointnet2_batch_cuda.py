@@ -87,7 +87,7 @@ def query_group_proj_grad_wrapper(b, c, n, npoints, nsample, grad_y, idx, grad_z
     return 1
 
 
-def three_interpolate_grad_csr_wrapper(b, c, n, m, grad_out, ptr, list_u, list_w, grad_points):
-    L.call("mgar_three_interpolate_grad_csr_batch", b, c, n, m, L.fptr(grad_out), L.iptr(ptr), L.iptr(list_u), L.fptr(list_w),
-           L.fptr(grad_points), L.stream_of(grad_out))
+def three_interpolate_grad_sorted_wrapper(b, c, n, m, grad_out, entries, grad_points):
+    L.call("mgar_three_interpolate_grad_sorted_batch", b, c, n, m, L.fptr(grad_out), L.iptr(entries), L.fptr(grad_points),
+           L.stream_of(grad_out))
     return 1

@@ -122,16 +122,16 @@ class ThreeInterpolate(Function):
         batch, chans, n_unknown = grad_out.size()
         grad_features = _new(grad_out, (batch, chans, ctx.n_known), torch.float32, 0.0)
         grad_out = grad_out.contiguous()
-        if grad_out.is_cuda and n_unknown <= 36864 and chans >= 16 and hasattr(pointnet2, "three_interpolate_grad_csr_wrapper"):
-            # inverted index (CSR by known point), built once and shared by all channels: no atomics
-            m = ctx.n_known
-            key = (idx.long() + (torch.arange(batch, device=idx.device) * m).view(-1, 1, 1)).view(-1)
-            order = torch.argsort(key, stable=True)
-            ptr = torch.zeros(batch * m + 1, dtype=torch.int32, device=idx.device)
-            ptr[1:] = torch.cumsum(torch.bincount(key, minlength=batch * m), 0).int()
-            list_u = ((order // 3) % n_unknown).int().contiguous()
-            list_w = weight.reshape(-1)[order].contiguous()
-            pointnet2.three_interpolate_grad_csr_wrapper(batch, chans, n_unknown, m, grad_out, ptr, list_u, list_w, grad_features)
+        m = ctx.n_known
+        if grad_out.is_cuda and n_unknown <= 36864 and m <= 65535 and chans >= 16 and hasattr(pointnet2, "three_interpolate_grad_sorted_wrapper"):
+            # inverted index: the 3n entries of every cloud sorted (stable) by known point, built once and
+            # shared by all channels -- every known point is then summed by one owner, without atomics
+            key = idx + (torch.arange(batch, device=idx.device, dtype=torch.int32) * m).view(-1, 1, 1) \
+                if batch * m < 2 ** 31 else idx.long() + (torch.arange(batch, device=idx.device) * m).view(-1, 1, 1)
+            order = torch.argsort(key.view(-1), stable=True)
+            packed = (idx.view(-1)[order] << 16) | ((order // 3) % n_unknown).int()
+            entries = torch.stack((packed, weight.reshape(-1)[order].view(torch.int32)), dim=1).contiguous()
+            pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features)
         else:
             pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, ctx.n_known, grad_out, idx, weight, grad_features)
         return grad_features, None, None
