@@ -223,11 +223,14 @@ int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsig
                             float *dx, void *stream);
 
 /* Weight gradient of a point-wise convolution on the exact-fp32 MFMA:
- *   dw[o][i] += sum_b sum_p dy[b,o,p] * x[b,i,p]      x (B,Cin,P), dy (B,Cout,P), dw (Cout,Cin)
+ *   dw[o][i] = sum_b sum_p dy[b,o,p] * x[b,i,p]       x (B,Cin,P), dy (B,Cout,P), dw (Cout,Cin)
  * (backward-weights of the Conv2d 1x1 layers of the shared MLPs, pointnet2_batch/
- * pointnet2_modules.py:86-92).  dw is ACCUMULATED into (caller zero-fills). */
-int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *dw,
-                           void *stream);
+ * pointnet2_modules.py:86-92).  dw is OVERWRITTEN.  Workgroup partials go through `workspace`
+ * (mgar_pointwise_dw_workspace_floats(B,Cin,Cout,P) floats) and are summed in a fixed order, so the
+ * result is reproducible run to run. */
+int mgar_pointwise_dw_workspace_floats(int B, int Cin, int Cout, int P);
+int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *workspace,
+                           float *dw, void *stream);
 
 /* MaxPool3dSamePadding.forward of the reference's I3D (model/backbone.py:99-131): zero "same"
  * padding + max pooling without materialising the padded tensor.  x (NC, T, H, W) -> y (NC, ceil(T/st),

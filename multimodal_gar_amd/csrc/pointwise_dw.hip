@@ -13,7 +13,10 @@
 //     16-byte loads (row stride 129 floats => the transposed operand reads are bank-conflict free);
 //   * each of its 4 waves takes 32 columns of the tile = 16 MFMA k-steps (K = 2 columns each) for
 //     every 32x32 output block; the Cout x Cin accumulator lives in registers for the whole kernel;
-//   * one flush at the end: float atomics on whole 128-byte rows of dW (the full-rate shape).
+//   * one flush at the end: every workgroup stores its partial Cout x Cin block to a workspace and a
+//     second small kernel sums the partials in workgroup order -- deterministic, and without the
+//     ~0.5 ms that 2048 workgroups x (Cout*Cin) float atomics on the SAME 1-4 K addresses cost
+//     (same-address atomics serialise in L2; measured as the size-independent floor of this kernel).
 // HBM-bound: 4*(Cin + Cout) bytes per column; MFMA time is ~4x below the streaming time.
 #include "common.hpp"
 
@@ -27,7 +30,7 @@ constexpr int DW_LD = DW_TP + 1;      // LDS row stride (floats)
 // OB x IB output blocks of 32 x 32 per workgroup (OB * IB <= 8)
 template <int OB, int IB>
 __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int Cin,
-                                                           int Cout, int P, float *__restrict__ dw) {
+                                                           int Cout, int P, float *__restrict__ partial) {
     extern __shared__ float lds[];                 // [(OB + IB) * 32][DW_LD]
     float *sy = lds;                               // dY rows of this workgroup's output blocks
     float *sx = lds + OB * 32 * DW_LD;             // X rows of this workgroup's input blocks
@@ -89,51 +92,113 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
         }
         __syncthreads();
     }
-    // ---- flush: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31] ----
+    // ---- combine the 4 waves in LDS (wave order), then wave 0 stores the workgroup's partial block ----
+    // (the staging area is free now: the loop ends with a barrier; 3 * OB*IB * 1024 floats fit in it)
+    if (wave > 0) {
+#pragma unroll
+        for (int a = 0; a < OB; ++a)
+#pragma unroll
+            for (int c = 0; c < IB; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds[(((wave - 1) * OB * IB + a * IB + c) * 16 + r) * 64 + lane] = acc[a][c][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    // D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]
 #pragma unroll
     for (int a = 0; a < OB; ++a)
 #pragma unroll
         for (int c = 0; c < IB; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                float v = acc[a][c][r];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += lds[((w * OB * IB + a * IB + c) * 16 + r) * 64 + lane];
                 const int o = o_base + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int i = i_base + c * 32 + (lane & 31);
-                if (o < Cout && i < Cin) atomicAdd(dw + (size_t)o * Cin + i, acc[a][c][r]);
+                if (o < Cout && i < Cin) partial[((size_t)blockIdx.x * Cout + o) * Cin + i] = v;
             }
 }
 
+// dw[e] = sum over the gx partials, in workgroup order.  256 threads = 64 outputs x 4 slices of gx.
+__global__ __launch_bounds__(256) void pointwise_dw_reduce_kernel(const float *__restrict__ partial, int gx, int n_out,
+                                                                  float *__restrict__ dw) {
+    __shared__ float part[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    const int per = (gx + 3) / 4, g0 = slice * per, g1 = min(g0 + per, gx);
+    float s = 0.f;
+    if (e < n_out) {
+        int g = g0;
+        for (; g + 4 <= g1; g += 4) {
+            const float a = partial[(size_t)g * n_out + e], b = partial[(size_t)(g + 1) * n_out + e];
+            const float c = partial[(size_t)(g + 2) * n_out + e], d = partial[(size_t)(g + 3) * n_out + e];
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; g < g1; ++g) s += partial[(size_t)g * n_out + e];
+    }
+    part[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && e < n_out) dw[e] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+
+static int dw_grid_x(int B, int Cin, int Cout, int P, int ob, int ib) {
+    const long long tiles = (long long)B * ((P + DW_TP - 1) / DW_TP);
+    const int gy = ceil_div(Cout, ob * 32), gz = ceil_div(Cin, ib * 32);
+    long long gx = 2048 / (gy * gz);                 // ~8 workgroups per CU in total ...
+    if (gx > (tiles + 3) / 4) gx = (tiles + 3) / 4;  // ... each with at least 4 tiles to stream
+    if (gx < 1) gx = 1;
+    return (int)gx;
+}
+static void dw_blocks(int Cin, int Cout, int &ob, int &ib) {
+    ob = Cout <= 32 ? 1 : 2;
+    ib = Cin <= 32 ? 1 : (Cin <= 64 ? 2 : 4);        // OB * IB <= 8
+}
+
 template <int OB, int IB>
-static void launch_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *dw, hipStream_t st) {
+static void launch_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *partial, hipStream_t st) {
     static bool attr_set = false;
     const int lds = (OB + IB) * 32 * DW_LD * (int)sizeof(float);
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)pointwise_dw_kernel<OB, IB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const long long tiles = (long long)B * ((P + DW_TP - 1) / DW_TP);
     const int gy = ceil_div(Cout, OB * 32), gz = ceil_div(Cin, IB * 32);
-    long long gx = 2048 / (gy * gz);                 // ~8 workgroups per CU in total
-    if (gx > tiles) gx = tiles;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((pointwise_dw_kernel<OB, IB>), dim3((unsigned)gx, gy, gz), dim3(256), lds, st, x, dy, B, Cin, Cout, P, dw);
+    const int gx = dw_grid_x(B, Cin, Cout, P, OB, IB);
+    hipLaunchKernelGGL((pointwise_dw_kernel<OB, IB>), dim3((unsigned)gx, gy, gz), dim3(256), lds, st, x, dy, B, Cin, Cout, P, partial);
 }
 
 }  // namespace mgar
 
 using namespace mgar;
 
+extern "C" __attribute__((visibility("default"))) int mgar_pointwise_dw_workspace_floats(int B, int Cin, int Cout, int P) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0) return 0;
+    int ob, ib;
+    dw_blocks(Cin, Cout, ob, ib);
+    return dw_grid_x(B, Cin, Cout, P, ob, ib) * Cout * Cin;   // <= 2048 * 64 * 256
+}
+
 extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin,
-                                                                            int Cout, int P, float *dw, void *stream) {
+                                                                            int Cout, int P, float *workspace, float *dw,
+                                                                            void *stream) {
     MGAR_REQUIRE(B >= 0 && Cin >= 0 && Cout >= 0 && P >= 0, "pointwise_conv_dw: negative size");
-    if ((long long)B * P == 0 || Cin == 0 || Cout == 0) return MGAR_OK;
-    MGAR_REQUIRE(x && dy && dw, "pointwise_conv_dw: null pointer");
+    if (Cin == 0 || Cout == 0) return MGAR_OK;
+    MGAR_REQUIRE(dw, "pointwise_conv_dw: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int ob = Cout <= 32 ? 1 : 2, ib = Cin <= 32 ? 1 : (Cin <= 64 ? 2 : 4);   // OB * IB <= 8
-    if (ob == 1 && ib == 1) launch_dw<1, 1>(x, dy, B, Cin, Cout, P, dw, st);
-    else if (ob == 1 && ib == 2) launch_dw<1, 2>(x, dy, B, Cin, Cout, P, dw, st);
-    else if (ob == 1 && ib == 4) launch_dw<1, 4>(x, dy, B, Cin, Cout, P, dw, st);
-    else if (ob == 2 && ib == 1) launch_dw<2, 1>(x, dy, B, Cin, Cout, P, dw, st);
-    else if (ob == 2 && ib == 2) launch_dw<2, 2>(x, dy, B, Cin, Cout, P, dw, st);
-    else launch_dw<2, 4>(x, dy, B, Cin, Cout, P, dw, st);
+    if ((long long)B * P == 0) {
+        (void)hipMemsetAsync(dw, 0, sizeof(float) * Cout * Cin, st);
+        return check_launch("pointwise_conv_dw: memset failed");
+    }
+    MGAR_REQUIRE(x && dy && workspace, "pointwise_conv_dw: null pointer");
+    int ob, ib;
+    dw_blocks(Cin, Cout, ob, ib);
+    if (ob == 1 && ib == 1) launch_dw<1, 1>(x, dy, B, Cin, Cout, P, workspace, st);
+    else if (ob == 1 && ib == 2) launch_dw<1, 2>(x, dy, B, Cin, Cout, P, workspace, st);
+    else if (ob == 1 && ib == 4) launch_dw<1, 4>(x, dy, B, Cin, Cout, P, workspace, st);
+    else if (ob == 2 && ib == 1) launch_dw<2, 1>(x, dy, B, Cin, Cout, P, workspace, st);
+    else if (ob == 2 && ib == 2) launch_dw<2, 2>(x, dy, B, Cin, Cout, P, workspace, st);
+    else launch_dw<2, 4>(x, dy, B, Cin, Cout, P, workspace, st);
+    const int gx = dw_grid_x(B, Cin, Cout, P, ob, ib), n_out = Cout * Cin;
+    hipLaunchKernelGGL(pointwise_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(256), 0, st, workspace, gx, n_out, dw);
     return check_launch("pointwise_conv_dw: launch failed");
 }

@@ -29,10 +29,7 @@ class _PointwiseConv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.bmm(w.t().unsqueeze(0).expand(dy.shape[0], -1, -1), dy)
         if ctx.needs_input_grad[1]:
-            x3c = x3.contiguous()
-            dw = torch.zeros_like(w)
-            L.call("mgar_pointwise_conv_dw", L.fptr(x3c), L.fptr(dy), x3c.shape[0], w.shape[1], w.shape[0], x3c.shape[2],
-                   L.fptr(dw), L.stream_of(dy))
+            dw = pointwise_dw(x3, dy)
         return dx, dw
 
 
@@ -43,9 +40,11 @@ def pointwise_dw(x3, dy):
     """sum_b dy[b] @ x3[b]^T -> (Cout, Cin) on csrc/pointwise_dw.hip (x3 (B, Cin, P), dy (B, Cout, P))."""
     from . import _lib as L
     x3, dy = x3.contiguous(), dy.contiguous()
-    dw = torch.zeros((dy.shape[1], x3.shape[1]), dtype=torch.float32, device=dy.device)
-    L.call("mgar_pointwise_conv_dw", L.fptr(x3), L.fptr(dy), x3.shape[0], x3.shape[1], dy.shape[1], x3.shape[2], L.fptr(dw),
-           L.stream_of(dy))
+    b, cin, p = x3.shape
+    cout = dy.shape[1]
+    dw = torch.empty((cout, cin), dtype=torch.float32, device=dy.device)
+    ws = torch.empty((max(1, L.raw("mgar_pointwise_dw_workspace_floats", b, cin, cout, p)),), dtype=torch.float32, device=dy.device)
+    L.call("mgar_pointwise_conv_dw", L.fptr(x3), L.fptr(dy), b, cin, cout, p, L.fptr(ws), L.fptr(dw), L.stream_of(dy))
     return dw
 
 

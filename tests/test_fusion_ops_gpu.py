@@ -241,10 +241,14 @@ def test_pointwise_conv_dw_matches_fp64(B, Cin, Cout, P):
     torch.manual_seed(Cin + Cout)
     x = torch.randn(B, Cin, P, device="cuda")
     dy = torch.randn(B, Cout, P, device="cuda")
-    dw = torch.zeros(Cout, Cin, device="cuda")
-    L.call("mgar_pointwise_conv_dw", L.fptr(x), L.fptr(dy), B, Cin, Cout, P, L.fptr(dw), L.stream_of(x))
+    dw = torch.full((Cout, Cin), float("nan"), device="cuda")       # the kernel overwrites
+    ws = torch.empty(L.raw("mgar_pointwise_dw_workspace_floats", B, Cin, Cout, P), device="cuda")
+    L.call("mgar_pointwise_conv_dw", L.fptr(x), L.fptr(dy), B, Cin, Cout, P, L.fptr(ws), L.fptr(dw), L.stream_of(x))
     want = torch.einsum("bop,bip->oi", dy.double(), x.double())
     close(dw, want, rtol=2e-5, atol=1e-3)
+    dw2 = torch.empty_like(dw)                                       # partials are summed in a fixed order
+    L.call("mgar_pointwise_conv_dw", L.fptr(x), L.fptr(dy), B, Cin, Cout, P, L.fptr(ws), L.fptr(dw2), L.stream_of(x))
+    assert torch.equal(dw, dw2)
 
 
 def test_conv1x1_uses_dw_kernel_and_matches_torch_conv():
