@@ -232,6 +232,24 @@ int mgar_pointwise_dw_workspace_floats(int B, int Cin, int Cout, int P);
 int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *workspace,
                            float *dw, void *stream);
 
+/* The same with the X operand activated on the fly: x := relu?(bn(x)) with the given BatchNorm
+ * statistics / affine (in_gamma, in_beta may be NULL = 1, 0; in_mean NULL = no activation), i.e. X
+ * is the PRE-BN output of the previous layer. */
+int mgar_pointwise_conv_dw_act(const float *x, const float *dy, int B, int Cin, int Cout, int P,
+                               const float *in_mean, const float *in_invstd, const float *in_gamma,
+                               const float *in_beta, int in_relu, float *workspace, float *dw, void *stream);
+
+/* One [BatchNorm -> ReLU -> Conv 1x1] step of the shared MLPs (pointnet2_batch/pointnet2_modules.py:
+ * 86-92, pointnet2_stack/pointnet2_modules.py:33-40) without materialising the activated tensor:
+ *   y[b,o,p] = sum_i w[o*w_row_stride + i*w_col_stride] * act_i(x[b,i,p])
+ *   act_i(v) = relu?(v * sc_i + sh_i), sc_i = in_invstd[i]*in_gamma[i], sh_i = in_beta[i] - in_mean[i]*sc_i
+ * (in_mean NULL = identity; in_gamma / in_beta NULL = 1 / 0).  With w read transposed (strides
+ * swapped) and no activation it is the data gradient dX = W^T dY.  x (B,Cin,P), y (B,Cout,P).
+ * Needs Cout <= 64, 1 <= Cin <= 256, P % 4 == 0 (MGAR_EUNSUPPORTED otherwise). */
+int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *w, int w_row_stride,
+                            int w_col_stride, int Cout, const float *in_mean, const float *in_invstd,
+                            const float *in_gamma, const float *in_beta, int in_relu, float *y, void *stream);
+
 /* MaxPool3dSamePadding.forward of the reference's I3D (model/backbone.py:99-131): zero "same"
  * padding + max pooling without materialising the padded tensor.  x (NC, T, H, W) -> y (NC, ceil(T/st),
  * ceil(H/sh), ceil(W/sw)).  Forward only (I3D is frozen in MGAR-net). */

@@ -57,6 +57,8 @@ _PROTOS = {
     "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_pointwise_conv_dw": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "mgar_pointwise_dw_workspace_floats": [_I, _I, _I, _I],
+    "mgar_pointwise_conv_dw_act": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "mgar_pointwise_conv_fwd": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_maxpool3d_same_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],

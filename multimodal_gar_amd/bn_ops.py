@@ -89,6 +89,70 @@ class _BnActMaxPool(Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+class _BnActConv(Function):
+    """y = W . [relu](batch_norm_train(x)) for x (B, C, P), W (Cout, C): one [BN -> ReLU -> Conv 1x1] step of
+    a shared MLP on csrc/pointwise_fwd.hip.  The activated tensor is never written: the forward
+    applies BN + ReLU to x while feeding the MFMA, the backward recomputes it inside the weight-
+    gradient kernel (csrc/pointwise_dw.hip); only the pre-BN x is saved."""
+
+    @staticmethod
+    def forward(ctx, x3, gamma, beta, mean, invstd, relu, w):
+        b, c, p = x3.shape
+        cout = w.shape[0]
+        w = w.contiguous()
+        y = torch.empty((b, cout, p), dtype=torch.float32, device=x3.device)
+        L.call("mgar_pointwise_conv_fwd", L.fptr(x3), b, c, p, L.fptr(w), c, 1, cout, L.fptr(mean), L.fptr(invstd),
+               L.fptr(gamma), L.fptr(beta), int(relu), L.fptr(y), L.stream_of(x3))
+        ctx.save_for_backward(x3, gamma, beta, mean, invstd, w)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x3, gamma, beta, mean, invstd, w = ctx.saved_tensors
+        b, c, p = x3.shape
+        cout = w.shape[0]
+        gy = gy.contiguous()
+        st = L.stream_of(x3)
+        dw = None
+        if ctx.needs_input_grad[6]:
+            dw = torch.empty_like(w)
+            wsd = torch.empty((max(1, L.raw("mgar_pointwise_dw_workspace_floats", b, c, cout, p)),), dtype=torch.float32,
+                              device=x3.device)
+            L.call("mgar_pointwise_conv_dw_act", L.fptr(x3), L.fptr(gy), b, c, cout, p, L.fptr(mean), L.fptr(invstd),
+                   L.fptr(gamma), L.fptr(beta), int(ctx.relu), L.fptr(wsd), L.fptr(dw), st)
+        # grad wrt the activated input: W^T gy (same kernel, W read transposed, no activation)
+        ga = torch.empty_like(x3)
+        L.call("mgar_pointwise_conv_fwd", L.fptr(gy), b, cout, p, L.fptr(w), 1, c, c, None, None, None, None, 0,
+               L.fptr(ga), st)
+        dx = torch.empty_like(x3)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = _workspace(x3, b, c, p)
+        L.call("mgar_bn_act_bwd", L.fptr(ga), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+               L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), st)
+        return dx, dgamma, dbeta, None, None, None, dw
+
+
+FUSED_CONV_MAX_CHANNELS = 64   # csrc/pointwise_fwd.hip: Cout <= 64 in both directions
+
+
+def bn_act_conv(x, bn, relu, conv):
+    """conv(relu?(bn(x))) for a bias-free kernel-size-1 ``conv`` in one fused step, or None if the
+    shapes are outside the fused kernel (the caller then runs bn_act and the GEMM separately)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() >= 3 and conv.bias is None):
+        return None
+    c, cout = x.shape[1], conv.out_channels
+    x3 = x.contiguous().flatten(2)
+    if c > FUSED_CONV_MAX_CHANNELS or cout > FUSED_CONV_MAX_CHANNELS or x3.shape[2] % 4 != 0 \
+            or x3.shape[0] * x3.shape[2] < (1 << 16):
+        return None
+    mean, invstd = _stats(x3, bn)
+    gamma, beta = _affine(bn, c, x.device)
+    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, conv.weight.view(cout, c))
+    return y.view(x.shape[0], cout, *x.shape[2:])
+
+
 def _affine(bn, c, device):
     if bn.affine:
         return bn.weight, bn.bias

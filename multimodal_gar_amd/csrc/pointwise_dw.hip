@@ -27,14 +27,37 @@ typedef float __attribute__((ext_vector_type(16))) f32x16;
 constexpr int DW_TP = 128;            // columns per tile
 constexpr int DW_LD = DW_TP + 1;      // LDS row stride (floats)
 
+// optional activation of the X operand on the fly: x := relu?(x * sc_i + sh_i) with the BatchNorm
+// arithmetic of bn_apply_kernel (csrc/bn_act.hip) -- X is then the PRE-BN output of the previous
+// layer and the activated tensor is never materialised (see csrc/pointwise_fwd.hip)
+struct DwAct {
+    const float *mean, *invstd, *gamma, *beta;
+    int relu;
+};
+
 // OB x IB output blocks of 32 x 32 per workgroup (OB * IB <= 8)
 template <int OB, int IB>
 __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int Cin,
-                                                           int Cout, int P, float *__restrict__ partial) {
+                                                           int Cout, int P, DwAct act, float *__restrict__ partial) {
     extern __shared__ float lds[];                 // [(OB + IB) * 32][DW_LD]
+    __shared__ float act_sc[IB * 32], act_sh[IB * 32];
     float *sy = lds;                               // dY rows of this workgroup's output blocks
     float *sx = lds + OB * 32 * DW_LD;             // X rows of this workgroup's input blocks
     const int o_base = blockIdx.y * OB * 32, i_base = blockIdx.z * IB * 32;
+    const bool has_act = act.mean != nullptr;
+    if (has_act) {
+        for (int r = threadIdx.x; r < IB * 32; r += 256) {
+            const int ch = i_base + r;
+            float sc = 1.f, sh = 0.f;
+            if (ch < Cin) {
+                sc = act.invstd[ch] * (act.gamma ? act.gamma[ch] : 1.f);
+                sh = (act.beta ? act.beta[ch] : 0.f) - act.mean[ch] * sc;
+            }
+            act_sc[r] = sc;
+            act_sh[r] = sh;
+        }
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tiles_per_b = (P + DW_TP - 1) / DW_TP;
     const long long total_tiles = (long long)B * tiles_per_b;
@@ -59,8 +82,14 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
                 const int ch = is_y ? o_base + row : i_base + row - OB * 32;
                 const int cmax = is_y ? Cout : Cin;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ch < cmax && p0 + c4 < P)
+                if (ch < cmax && p0 + c4 < P) {
                     v = *reinterpret_cast<const float4 *>((is_y ? dy : x) + ((size_t)b * cmax + ch) * P + p0 + c4);
+                    if (has_act && !is_y) {
+                        const float sc = act_sc[row - OB * 32], sh = act_sh[row - OB * 32];
+                        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                        if (act.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    }
+                }
                 float *d = lds + row * DW_LD + c4;
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
@@ -70,7 +99,15 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
                 const bool is_y = row < OB * 32;
                 const int ch = is_y ? o_base + row : i_base + row - OB * 32;
                 const int cmax = is_y ? Cout : Cin;
-                lds[row * DW_LD + cc] = (ch < cmax && p0 + cc < P) ? (is_y ? dy : x)[((size_t)b * cmax + ch) * P + p0 + cc] : 0.f;
+                float v = 0.f;
+                if (ch < cmax && p0 + cc < P) {
+                    v = (is_y ? dy : x)[((size_t)b * cmax + ch) * P + p0 + cc];
+                    if (has_act && !is_y) {
+                        v = v * act_sc[row - OB * 32] + act_sh[row - OB * 32];
+                        if (act.relu) v = fmaxf(v, 0.f);
+                    }
+                }
+                lds[row * DW_LD + cc] = v;
             }
         }
         __syncthreads();
@@ -155,7 +192,8 @@ static void dw_blocks(int Cin, int Cout, int &ob, int &ib) {
 }
 
 template <int OB, int IB>
-static void launch_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, float *partial, hipStream_t st) {
+static void launch_dw(const float *x, const float *dy, int B, int Cin, int Cout, int P, const DwAct &act, float *partial,
+                      hipStream_t st) {
     static bool attr_set = false;
     const int lds = (OB + IB) * 32 * DW_LD * (int)sizeof(float);
     if (!attr_set) {
@@ -164,7 +202,7 @@ static void launch_dw(const float *x, const float *dy, int B, int Cin, int Cout,
     }
     const int gy = ceil_div(Cout, OB * 32), gz = ceil_div(Cin, IB * 32);
     const int gx = dw_grid_x(B, Cin, Cout, P, OB, IB);
-    hipLaunchKernelGGL((pointwise_dw_kernel<OB, IB>), dim3((unsigned)gx, gy, gz), dim3(256), lds, st, x, dy, B, Cin, Cout, P, partial);
+    hipLaunchKernelGGL((pointwise_dw_kernel<OB, IB>), dim3((unsigned)gx, gy, gz), dim3(256), lds, st, x, dy, B, Cin, Cout, P, act, partial);
 }
 
 }  // namespace mgar
@@ -178,27 +216,37 @@ extern "C" __attribute__((visibility("default"))) int mgar_pointwise_dw_workspac
     return dw_grid_x(B, Cin, Cout, P, ob, ib) * Cout * Cin;   // <= 2048 * 64 * 256
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin,
-                                                                            int Cout, int P, float *workspace, float *dw,
-                                                                            void *stream) {
+extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_dw_act(const float *x, const float *dy, int B, int Cin,
+                                                                                int Cout, int P, const float *in_mean,
+                                                                                const float *in_invstd, const float *in_gamma,
+                                                                                const float *in_beta, int in_relu,
+                                                                                float *workspace, float *dw, void *stream) {
     MGAR_REQUIRE(B >= 0 && Cin >= 0 && Cout >= 0 && P >= 0, "pointwise_conv_dw: negative size");
     if (Cin == 0 || Cout == 0) return MGAR_OK;
     MGAR_REQUIRE(dw, "pointwise_conv_dw: null pointer");
+    MGAR_REQUIRE(in_mean == nullptr || in_invstd != nullptr, "pointwise_conv_dw: in_mean without in_invstd");
     hipStream_t st = (hipStream_t)stream;
     if ((long long)B * P == 0) {
         (void)hipMemsetAsync(dw, 0, sizeof(float) * Cout * Cin, st);
         return check_launch("pointwise_conv_dw: memset failed");
     }
     MGAR_REQUIRE(x && dy && workspace, "pointwise_conv_dw: null pointer");
+    const DwAct act{in_mean, in_invstd, in_gamma, in_beta, in_relu};
     int ob, ib;
     dw_blocks(Cin, Cout, ob, ib);
-    if (ob == 1 && ib == 1) launch_dw<1, 1>(x, dy, B, Cin, Cout, P, workspace, st);
-    else if (ob == 1 && ib == 2) launch_dw<1, 2>(x, dy, B, Cin, Cout, P, workspace, st);
-    else if (ob == 1 && ib == 4) launch_dw<1, 4>(x, dy, B, Cin, Cout, P, workspace, st);
-    else if (ob == 2 && ib == 1) launch_dw<2, 1>(x, dy, B, Cin, Cout, P, workspace, st);
-    else if (ob == 2 && ib == 2) launch_dw<2, 2>(x, dy, B, Cin, Cout, P, workspace, st);
-    else launch_dw<2, 4>(x, dy, B, Cin, Cout, P, workspace, st);
+    if (ob == 1 && ib == 1) launch_dw<1, 1>(x, dy, B, Cin, Cout, P, act, workspace, st);
+    else if (ob == 1 && ib == 2) launch_dw<1, 2>(x, dy, B, Cin, Cout, P, act, workspace, st);
+    else if (ob == 1 && ib == 4) launch_dw<1, 4>(x, dy, B, Cin, Cout, P, act, workspace, st);
+    else if (ob == 2 && ib == 1) launch_dw<2, 1>(x, dy, B, Cin, Cout, P, act, workspace, st);
+    else if (ob == 2 && ib == 2) launch_dw<2, 2>(x, dy, B, Cin, Cout, P, act, workspace, st);
+    else launch_dw<2, 4>(x, dy, B, Cin, Cout, P, act, workspace, st);
     const int gx = dw_grid_x(B, Cin, Cout, P, ob, ib), n_out = Cout * Cin;
     hipLaunchKernelGGL(pointwise_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(256), 0, st, workspace, gx, n_out, dw);
     return check_launch("pointwise_conv_dw: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_dw(const float *x, const float *dy, int B, int Cin,
+                                                                            int Cout, int P, float *workspace, float *dw,
+                                                                            void *stream) {
+    return mgar_pointwise_conv_dw_act(x, dy, B, Cin, Cout, P, nullptr, nullptr, nullptr, nullptr, 0, workspace, dw, stream);
 }

@@ -1,0 +1,187 @@
+// pointwise_fwd.hip -- point-wise (kernel-size-1) convolution with the PREVIOUS layer's BatchNorm +
+// ReLU applied to its input on the fly, on the exact-fp32 MFMA, gfx950.
+//
+//   y[b, o, p] = sum_i W[o, i] * act_i(x[b, i, p])        x (B, Cin, P), y (B, Cout, P)
+//   act_i(v)   = relu?(v * sc_i + sh_i),  sc_i = invstd_i * gamma_i,  sh_i = beta_i - mean_i * sc_i
+//                (the arithmetic of bn_apply_kernel, csrc/bn_act.hip), or the identity
+//
+// This is one [BN -> ReLU -> Conv2d 1x1] step of the reference's shared MLPs (pointnet2_batch/
+// pointnet2_modules.py:86-92, pointnet2_stack/pointnet2_modules.py:33-40, voxel_pool_modules.py:41-
+// 52) without ever writing the activated tensor: the layer input is the previous layer's PRE-BN
+// output.  The same kernel with W read transposed and the identity activation is the data gradient
+// of the layer (dX = W^T dY).
+//
+// As a GEMM it is skinny -- Cout, Cin <= 64, up to 15.7 M columns at config c3 -- and HBM-bound
+// (4*(Cin + Cout) bytes per column against 2*Cin*Cout flops: 5..16 flop/byte); the library runs these
+// shapes at 1.2-1.6 TB/s.  Here:
+//   * the B operand of v_mfma_f32_32x32x2_f32 (k = channel pair, n = column) is exactly the layout
+//     of a row-major (channel, column) tensor, so x goes global -> registers -> MFMA with no LDS
+//     staging: lane (l, h) loads a float4 = columns 4l..4l+3 of channel 2k+h (512 contiguous bytes
+//     per half-wave), and component j of the float4 feeds the j-th of four interleaved 32-column
+//     sub-tiles; the D registers of the four sub-tiles then hold columns 4l..4l+3 again, so y is
+//     written with 16-byte stores;
+//   * W (<= 32 KB) and the per-channel (sc, sh) sit in LDS, read conflict-free as the A operand;
+//   * every wave owns whole 128-column tiles and software-pipelines them: the loads of the next
+//     16-channel slab are in flight while the MFMAs of the current one run.
+#include "common.hpp"
+
+namespace mgar {
+
+typedef float __attribute__((ext_vector_type(16))) f32x16;
+
+constexpr int PF_KC = 16;     // channels per slab (8 MFMA k-steps)
+constexpr int PF_COLS = 128;  // columns per wave tile
+
+struct PfArgs {
+    const float *x;
+    const float *w;
+    const float *mean, *invstd, *gamma, *beta;  // input activation (mean == nullptr: identity)
+    float *y;
+    int B, Cin, Cout, P;
+    int w_rs, w_cs;  // W[o, i] = w[o * w_rs + i * w_cs]
+    int relu;
+};
+
+template <int OB>
+__global__ __launch_bounds__(256) void pointwise_fwd_kernel(PfArgs a) {
+    constexpr int WLD = OB == 1 ? 32 : 96;  // LDS row stride of W: the two half-waves hit disjoint banks
+    extern __shared__ float lds[];          // [nkc*16][WLD] weights, then [nkc*16][2] (sc, sh)
+    const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
+    float *wl = lds;
+    float *act = lds + (size_t)nkc * PF_KC * WLD;
+    for (int e = threadIdx.x; e < nkc * PF_KC * WLD; e += 256) {
+        const int ch = e / WLD, o = e - ch * WLD;
+        wl[e] = (ch < a.Cin && o < a.Cout) ? a.w[(size_t)o * a.w_rs + (size_t)ch * a.w_cs] : 0.f;
+    }
+    for (int ch = threadIdx.x; ch < nkc * PF_KC; ch += 256) {
+        float sc = 1.f, sh = 0.f;
+        if (a.mean && ch < a.Cin) {
+            sc = a.invstd[ch] * (a.gamma ? a.gamma[ch] : 1.f);
+            sh = (a.beta ? a.beta[ch] : 0.f) - a.mean[ch] * sc;
+        }
+        act[2 * ch] = sc;
+        act[2 * ch + 1] = sh;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int tiles_per_b = (a.P + PF_COLS - 1) / PF_COLS;
+    const long long ntiles = (long long)a.B * tiles_per_b;
+    const long long wave_id = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
+    if (wave_id >= ntiles) return;
+    const long long my_tiles = (ntiles - wave_id + nwaves - 1) / nwaves;
+    const long long steps = my_tiles * nkc;
+    const bool has_act = a.mean != nullptr, relu = a.relu != 0;
+
+    f32x16 acc[OB][4];
+#pragma unroll
+    for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ob][j][r] = 0.f;
+
+    // slab loads of step s (tile s / nkc of this wave, channel slab s % nkc)
+    auto issue = [&](long long s, float4 (&buf)[8]) {
+        const long long t = wave_id + (s / nkc) * nwaves;
+        const int kc = (int)(s % nkc);
+        const int b = (int)(t / tiles_per_b);
+        const int p = (int)(t - (long long)b * tiles_per_b) * PF_COLS + 4 * l;
+        const float *src = a.x + ((size_t)b * a.Cin + kc * PF_KC + h) * a.P + p;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int ch = kc * PF_KC + 2 * ks + h;
+            buf[ks] = (ch < a.Cin && p < a.P) ? *reinterpret_cast<const float4 *>(src + (size_t)2 * ks * a.P)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto compute = [&](long long s, float4 (&buf)[8]) {
+        const int kc = (int)(s % nkc);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const int ch = kc * PF_KC + 2 * ks + h;
+            float4 v = buf[ks];
+            if (has_act) {
+                const float sc = act[2 * ch], sh = act[2 * ch + 1];
+                v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (ch >= a.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);   // padding channels stay zero (W is zero there too)
+            }
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob) {
+                const float wa = wl[ch * WLD + ob * 32 + l];
+                acc[ob][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v.x, acc[ob][0], 0, 0, 0);
+                acc[ob][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v.y, acc[ob][1], 0, 0, 0);
+                acc[ob][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v.z, acc[ob][2], 0, 0, 0);
+                acc[ob][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, v.w, acc[ob][3], 0, 0, 0);
+            }
+        }
+        if (kc == nkc - 1) {  // tile finished: D[row = (r&3) + 8*(r>>2) + 4*h][col = l] of sub-tile j = column 4l + j
+            const long long t = wave_id + (s / nkc) * nwaves;
+            const int b = (int)(t / tiles_per_b);
+            const int p = (int)(t - (long long)b * tiles_per_b) * PF_COLS + 4 * l;
+#pragma unroll
+            for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (o < a.Cout && p < a.P)
+                        *reinterpret_cast<float4 *>(a.y + ((size_t)b * a.Cout + o) * a.P + p) =
+                            make_float4(acc[ob][0][r], acc[ob][1][r], acc[ob][2][r], acc[ob][3][r]);
+                    acc[ob][0][r] = 0.f; acc[ob][1][r] = 0.f; acc[ob][2][r] = 0.f; acc[ob][3][r] = 0.f;
+                }
+        }
+    };
+
+    float4 buf0[8], buf1[8];
+    issue(0, buf0);
+    for (long long s = 0; s < steps; s += 2) {
+        if (s + 1 < steps) issue(s + 1, buf1);
+        compute(s, buf0);
+        if (s + 1 < steps) {
+            if (s + 2 < steps) issue(s + 2, buf0);
+            compute(s + 1, buf1);
+        }
+    }
+}
+
+template <int OB>
+static void launch_pf(const PfArgs &a, hipStream_t st) {
+    constexpr int WLD = OB == 1 ? 32 : 96;
+    const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
+    const int lds = nkc * PF_KC * (WLD + 2) * (int)sizeof(float);
+    static int attr_lds = 0;
+    if (lds > 65536 && lds > attr_lds) {
+        (void)hipFuncSetAttribute((const void *)pointwise_fwd_kernel<OB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_lds = lds;
+    }
+    const long long ntiles = (long long)a.B * ((a.P + PF_COLS - 1) / PF_COLS);
+    long long wgs = (ntiles + 3) / 4;
+    if (wgs > 2048) wgs = 2048;   // 8 workgroups per CU; waves stride over the tiles
+    hipLaunchKernelGGL((pointwise_fwd_kernel<OB>), dim3((unsigned)wgs), dim3(256), lds, st, a);
+}
+
+}  // namespace mgar
+
+using namespace mgar;
+
+extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *w,
+                                                                             int w_row_stride, int w_col_stride, int Cout,
+                                                                             const float *in_mean, const float *in_invstd,
+                                                                             const float *in_gamma, const float *in_beta,
+                                                                             int in_relu, float *y, void *stream) {
+    MGAR_REQUIRE(B >= 0 && Cin >= 0 && Cout >= 0 && P >= 0, "pointwise_conv_fwd: negative size");
+    if ((long long)B * P == 0 || Cout == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && w && y, "pointwise_conv_fwd: null pointer");
+    MGAR_REQUIRE(in_mean == nullptr || in_invstd != nullptr, "pointwise_conv_fwd: in_mean without in_invstd");
+    if (Cout > 64 || Cin > 256 || Cin == 0 || (P & 3) != 0) {
+        set_error("pointwise_conv_fwd: needs 1 <= Cin <= 256, Cout <= 64 and P % 4 == 0 (use the library GEMM otherwise)");
+        return MGAR_EUNSUPPORTED;
+    }
+    PfArgs a{x, w, in_mean, in_invstd, in_gamma, in_beta, y, B, Cin, Cout, P, w_row_stride, w_col_stride, in_relu};
+    hipStream_t st = (hipStream_t)stream;
+    if (Cout <= 32) launch_pf<1>(a, st);
+    else launch_pf<2>(a, st);
+    return check_launch("pointwise_conv_fwd: launch failed");
+}

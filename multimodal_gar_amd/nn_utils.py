@@ -80,6 +80,8 @@ class PointwiseSequential(nn.Sequential):
     csrc/bn_act.hip; ``forward_maxpool`` additionally folds the max over the last axis (nsample)
     into the last BatchNorm + ReLU so that activation is never written."""
 
+    fuse_bn_conv = True
+
     def _run(self, x, pool_last, start=0):
         from . import bn_ops
         layers = list(self)
@@ -94,6 +96,14 @@ class PointwiseSequential(nn.Sequential):
                 relu = i + 1 < n and isinstance(layers[i + 1], nn.ReLU)
                 last = i + (2 if relu else 1) >= n
                 y = None
+                nxt = i + (2 if relu else 1)
+                if nxt < n and _is_pointwise(layers[nxt]) and self.fuse_bn_conv:
+                    # [BN -> ReLU -> next conv] in one pass; the activated tensor is never written
+                    y = bn_ops.bn_act_conv(x, layer, relu, layers[nxt])
+                    if y is not None:
+                        x = y
+                        i = nxt + 1
+                        continue
                 if pool_last and last and x.dim() == 4:
                     y = bn_ops.bn_act_maxpool(x, layer, relu)
                     pooled = y is not None

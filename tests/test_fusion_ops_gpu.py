@@ -251,6 +251,99 @@ def test_pointwise_conv_dw_matches_fp64(B, Cin, Cout, P):
     assert torch.equal(dw, dw2)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,P", [(3, 16, 16, 4096), (2, 32, 64, 8192), (1, 12, 24, 1776), (5, 7, 64, 1000),
+                                          (2, 131, 32, 20000), (2, 64, 64, 3004), (120, 16, 32, 2048), (1, 1, 1, 4)])
+@pytest.mark.parametrize("act", [None, "bn", "bn_relu"])
+def test_pointwise_conv_fwd_matches_fp64(B, Cin, Cout, P, act):
+    """y = W . act(x) on the fp32 MFMA (csrc/pointwise_fwd.hip), plain and transposed weights."""
+    from multimodal_gar_amd import _lib as L
+    torch.manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, P, device="cuda")
+    w = torch.randn(Cout, Cin, device="cuda")
+    mean, var = torch.randn(Cin, device="cuda"), torch.rand(Cin, device="cuda") + 0.5
+    invstd = torch.rsqrt(var)
+    gamma, beta = torch.randn(Cin, device="cuda"), torch.randn(Cin, device="cuda")
+    y = torch.full((B, Cout, P), float("nan"), device="cuda")
+    null = None
+    L.call("mgar_pointwise_conv_fwd", L.fptr(x), B, Cin, P, L.fptr(w), Cin, 1, Cout,
+           L.fptr(mean) if act else null, L.fptr(invstd) if act else null, L.fptr(gamma) if act else null,
+           L.fptr(beta) if act else null, int(act == "bn_relu"), L.fptr(y), L.stream_of(x))
+    xa = x.double()
+    if act:
+        xa = (xa - mean.double().view(1, -1, 1)) * invstd.double().view(1, -1, 1) * gamma.double().view(1, -1, 1) + beta.double().view(1, -1, 1)
+        if act == "bn_relu":
+            xa = xa.clamp_min(0)
+    want = torch.einsum("oi,bip->bop", w.double(), xa)
+    close(y, want, rtol=2e-5, atol=1e-4)
+    if act is None:      # transposed read of the same weights: x2 (B, Cout, P) -> (B, Cin, P), needs Cin <= 64
+        if Cin <= 64:
+            g = torch.randn(B, Cout, P, device="cuda")
+            gx = torch.full((B, Cin, P), float("nan"), device="cuda")
+            L.call("mgar_pointwise_conv_fwd", L.fptr(g), B, Cout, P, L.fptr(w), 1, Cin, Cin, null, null, null, null, 0,
+                   L.fptr(gx), L.stream_of(x))
+            close(gx, torch.einsum("oi,bop->bip", w.double(), g.double()), rtol=2e-5, atol=1e-4)
+
+
+def test_pointwise_conv_fwd_rejects_unsupported():
+    from multimodal_gar_amd import _lib as L
+    x = torch.zeros(1, 8, 6, device="cuda"); w = torch.zeros(4, 8, device="cuda"); y = torch.zeros(1, 4, 6, device="cuda")
+    with pytest.raises(L.MgarError):
+        L.call("mgar_pointwise_conv_fwd", L.fptr(x), 1, 8, 6, L.fptr(w), 8, 1, 4, None, None, None, None, 0, L.fptr(y), L.stream_of(x))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,P", [(2, 32, 64, 8192), (1, 12, 24, 1776), (3, 64, 16, 1001)])
+def test_pointwise_conv_dw_act_matches_fp64(B, Cin, Cout, P):
+    from multimodal_gar_amd import _lib as L
+    torch.manual_seed(5)
+    x = torch.randn(B, Cin, P, device="cuda"); dy = torch.randn(B, Cout, P, device="cuda")
+    mean, invstd = torch.randn(Cin, device="cuda"), torch.rand(Cin, device="cuda") + 0.5
+    gamma, beta = torch.randn(Cin, device="cuda"), torch.randn(Cin, device="cuda")
+    dw = torch.empty(Cout, Cin, device="cuda")
+    ws = torch.empty(L.raw("mgar_pointwise_dw_workspace_floats", B, Cin, Cout, P), device="cuda")
+    L.call("mgar_pointwise_conv_dw_act", L.fptr(x), L.fptr(dy), B, Cin, Cout, P, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+           L.fptr(beta), 1, L.fptr(ws), L.fptr(dw), L.stream_of(x))
+    xa = ((x.double() - mean.double().view(1, -1, 1)) * invstd.double().view(1, -1, 1) * gamma.double().view(1, -1, 1)
+          + beta.double().view(1, -1, 1)).clamp_min(0)
+    close(dw, torch.einsum("bop,bip->oi", dy.double(), xa), rtol=2e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("chans,shape", [((19, 16, 16, 32), (4, 19, 1024, 16)), ((35, 32, 32, 64), (2, 35, 700, 32)),
+                                         ((8, 64, 48), (3, 8, 50000))])
+def test_shared_mlp_fused_bn_conv_matches_unfused(chans, shape):
+    """PointwiseSequential with the [BN -> ReLU -> conv] fusion vs the same module without it vs fp64 torch."""
+    import copy
+    from multimodal_gar_amd.nn_utils import PointwiseSequential
+    torch.manual_seed(31)
+    two_d = len(shape) == 4
+    layers = []
+    for cin, cout in zip(chans[:-1], chans[1:]):
+        layers += [(torch.nn.Conv2d if two_d else torch.nn.Conv1d)(cin, cout, 1, bias=False),
+                   (torch.nn.BatchNorm2d if two_d else torch.nn.BatchNorm1d)(cout), torch.nn.ReLU()]
+    mlp = PointwiseSequential(*layers).cuda().train()
+    for m in mlp.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            torch.nn.init.normal_(m.weight, 1.0, 0.3); torch.nn.init.normal_(m.bias, 0.0, 0.3)
+    plain = copy.deepcopy(mlp); plain.fuse_bn_conv = False
+    ref = torch.nn.Sequential(*[copy.deepcopy(m) for m in mlp]).double().cpu().train()
+    x = torch.randn(*shape, device="cuda")
+    outs = []
+    for mod, inp in ((mlp, x.clone().requires_grad_(True)), (plain, x.clone().requires_grad_(True)),
+                     (ref, x.detach().double().cpu().requires_grad_(True))):
+        y = mod.forward_maxpool(inp) if (two_d and mod is not ref) else mod(inp)
+        if mod is ref and two_d:
+            y = y.max(dim=3).values
+        g = torch.linspace(-1, 1, y.numel(), dtype=y.dtype, device=y.device).view(y.shape)
+        y.backward(g)
+        outs.append((y, inp.grad, [p.grad for p in mod.parameters()]))
+    for other in (outs[1], outs[2]):
+        close(outs[0][0], other[0], rtol=2e-4)
+        close(outs[0][1], other[1], rtol=5e-4)
+        for a, b in zip(outs[0][2], other[2]):
+            close(a, b, rtol=5e-4)
+    for bn_f, bn_p in zip([m for m in mlp if hasattr(m, "running_mean")], [m for m in plain if hasattr(m, "running_mean")]):
+        close(bn_f.running_mean, bn_p.running_mean); close(bn_f.running_var, bn_p.running_var)
+
+
 def test_conv1x1_uses_dw_kernel_and_matches_torch_conv():
     from multimodal_gar_amd.nn_utils import conv1x1
     torch.manual_seed(9)
