@@ -2,7 +2,7 @@
 """Times individual HIP kernels of libmgar_hip.so at BASELINE config c3 shapes (events on the launch
 stream).  Also the command run under ``rocprofv3 --pmc ...`` to collect HBM traffic per kernel:
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out -- python tools/microbench.py --only fps
-Usage: python tools/microbench.py [--frames 120] [--only fps,ball,nn,interp,bn,qg,dw] [--iters 5]
+Usage: python tools/microbench.py [--frames 120] [--only fps,ball,nn,interp,bn,qg,dw,pw] [--iters 5]
 """
 import argparse
 import os
@@ -28,7 +28,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=120)
     ap.add_argument("--points", type=int, default=16384)
-    ap.add_argument("--only", default="fps,ball,nn,interp,bn,qg,dw")
+    ap.add_argument("--only", default="fps,ball,nn,interp,bn,qg,dw,pw")
     ap.add_argument("--iters", type=int, default=5)
     a = ap.parse_args()
     only = set(a.only.split(","))
@@ -101,6 +101,20 @@ def main():
     if "dw" in only:
         x = torch.randn(f, 32, m * 32, device="cuda"); dy = torch.randn(f, 64, m * 32, device="cuda")
         rec("pointwise_dw Cin=32 Cout=64 P=%d" % (m * 32), timeit(lambda: nn_utils.pointwise_dw(x, dy), a.iters), x.numel() * 4 + dy.numel() * 4)
+        del x, dy
+    if "pw" in only:
+        from multimodal_gar_amd import _lib as L
+        for cin, cout, ns in ((16, 16, 16), (16, 32, 16), (32, 32, 32), (32, 64, 32), (64, 64, 16)):
+            p = m * ns
+            x = torch.randn(f, cin, p, device="cuda"); w = torch.randn(cout, cin, device="cuda")
+            y = torch.empty(f, cout, p, device="cuda")
+            mean = torch.zeros(cin, device="cuda"); invstd = torch.ones(cin, device="cuda")
+            fn = lambda: L.call("mgar_pointwise_conv_fwd", L.fptr(x), f, cin, p, L.fptr(w), cin, 1, cout, L.fptr(mean),  # noqa: E731
+                                L.fptr(invstd), None, None, 1, L.fptr(y), L.stream_of(x))
+            rec("pointwise_conv_fwd bn+relu %d->%d P=%d" % (cin, cout, p), timeit(fn, a.iters), (x.numel() + y.numel()) * 4)
+            we = w.unsqueeze(0).expand(f, -1, -1)
+            rec("   library bmm %d->%d (no activation)" % (cin, cout), timeit(lambda: torch.bmm(we, x, out=y), a.iters), (x.numel() + y.numel()) * 4)
+            del x, y
 
 
 if __name__ == "__main__":
