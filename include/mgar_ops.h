@@ -186,12 +186,24 @@ int mgar_query_group_proj_batch_fwd(int b, int c, int n, int npoints, int nsampl
                                     float *rel_out, float *y_out, void *stream);
 int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_y,
                                     const int *idx, float *grad_zf, void *stream);
+/* stack layout: zf / grad_zf rows have leading dimension zf_ld >= C floats, so the projections of
+ * several scales (multi-scale grouping) can live side by side in one (N, sum C_k) matrix produced by
+ * one GEMM over the shared features. */
 int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
-                                    const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf,
+                                    const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, int zf_ld,
                                     const float *wx, const int *idx, float *rel_out, float *y_out, void *stream);
 int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
                                     const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf,
-                                    void *stream);
+                                    int zf_ld, void *stream);
+
+/* Weight gradient of that projection on the exact-fp32 MFMA, stacked (row-major) operands:
+ *   dw[o][i] = sum_n a[n*lda + o] * f[n*ldf + i]      a (N,Co) = grad_zf, f (N,Ci) = features
+ * dw (Co,Ci) is OVERWRITTEN; partial sums go through `workspace`
+ * (mgar_rowmajor_dw_workspace_floats(N,Co,Ci) floats) and are added in a fixed order.
+ * Needs Co <= 96, Ci <= 128 (MGAR_EUNSUPPORTED otherwise). */
+int mgar_rowmajor_dw_workspace_floats(long long N, int Co, int Ci);
+int mgar_rowmajor_dw(const float *a, int lda, const float *f, int ldf, long long N, int Co, int Ci,
+                     float *workspace, float *dw, void *stream);
 
 /* ========== fused BatchNorm(train) + ReLU + max-over-nsample ========== */
 

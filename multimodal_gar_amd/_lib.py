@@ -19,7 +19,7 @@ if not os.path.exists(LIB_PATH):
 
 _cdll = ctypes.CDLL(LIB_PATH)
 
-_I, _F, _P = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_I, _F, _P, _LL = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_longlong
 
 # name -> argument ctypes, in the order of include/mgar_ops.h
 _PROTOS = {
@@ -47,8 +47,10 @@ _PROTOS = {
     "mgar_query_group_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_query_group_proj_batch_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_query_group_proj_batch_bwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "mgar_query_group_proj_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "mgar_query_group_proj_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_proj_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_query_group_proj_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
+    "mgar_rowmajor_dw_workspace_floats": [_LL, _I, _I],
+    "mgar_rowmajor_dw": [_P, _I, _P, _I, _LL, _I, _I, _P, _P, _P],
     "mgar_bn_workspace_floats": [_I, _I, _I],
     "mgar_bn_train_stats": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P],
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],

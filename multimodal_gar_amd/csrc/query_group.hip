@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
                                                            const int *__restrict__ xyz_batch_cnt,
                                                            const float *__restrict__ new_xyz,
                                                            const int *__restrict__ new_xyz_batch_cnt,
-                                                           const float *__restrict__ features,
+                                                           const float *__restrict__ features, int ld,
                                                            const float *__restrict__ wx, const int *__restrict__ idx,
                                                            float *__restrict__ rel_out, float *__restrict__ y_out) {
     __shared__ QsTile t;
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
             const int src = t.src_row[cl];
             float v = 0.f;
             if (src >= 0 && ci < nch) {
-                v = features[(size_t)src * C + c0 + ci];
+                v = features[(size_t)src * ld + c0 + ci];
                 if (wx) {
                     const float *w = wx + (size_t)(c0 + ci) * 3;
                     v += w[0] * t.rel[cl][0] + w[1] * t.rel[cl][1] + w[2] * t.rel[cl][2];
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, 
                                                            const int *__restrict__ idx,
                                                            const int *__restrict__ new_xyz_batch_cnt,
                                                            const int *__restrict__ xyz_batch_cnt,
-                                                           float *__restrict__ grad_features) {
+                                                           float *__restrict__ grad_features, int ld) {
     __shared__ QsTile t;
     int col0;
     const int ncol = qs_prologue(t, B, M, nsample, idx, new_xyz_batch_cnt, xyz_batch_cnt, col0);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, 
         for (int e = threadIdx.x; e < ncol * QS_CH; e += 256) {      // lanes along c: contiguous atomic pieces
             const int cl = e / QS_CH, ci = e - cl * QS_CH;
             const int src = t.src_row[cl];
-            if (src >= 0 && ci < nch) atomicAdd(grad_features + (size_t)src * C + c0 + ci, t.tile[cl][ci]);
+            if (src >= 0 && ci < nch) atomicAdd(grad_features + (size_t)src * ld + c0 + ci, t.tile[cl][ci]);
         }
         __syncthreads();
     }
@@ -290,26 +290,26 @@ QG_API int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int
 }
 
 static int qg_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt, const float *new_xyz,
-                        const int *new_xyz_batch_cnt, const float *features, const float *wx, const int *idx, float *rel_out,
-                        float *y_out, void *stream, const char *what) {
+                        const int *new_xyz_batch_cnt, const float *features, int ld, const float *wx, const int *idx,
+                        float *rel_out, float *y_out, void *stream, const char *what) {
     MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group (stack) fwd: negative size");
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0) return MGAR_OK;
     MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && (features || C == 0) && (y_out || C == 0) &&
                      (rel_out || y_out), "query_group (stack) fwd: null pointer");
     hipLaunchKernelGGL(qg_stack_fwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
-                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, wx, idx, rel_out, y_out);
+                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, ld, wx, idx, rel_out, y_out);
     return check_launch(what);
 }
 
 static int qg_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx, const int *new_xyz_batch_cnt,
-                        const int *xyz_batch_cnt, float *grad_features, void *stream, const char *what) {
-    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group (stack) bwd: negative size");
+                        const int *xyz_batch_cnt, float *grad_features, int ld, void *stream, const char *what) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0 && ld >= C, "query_group (stack) bwd: negative size or ld < C");
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0 || C == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_y && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group (stack) bwd: null pointer");
     hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
-                       grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features);
+                       grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features, ld);
     return check_launch(what);
 }
 
@@ -317,26 +317,27 @@ QG_API int mgar_query_group_stack_fwd(int B, int M, int C, int nsample, const fl
                                       const float *new_xyz, const int *new_xyz_batch_cnt, const float *features, const int *idx,
                                       float *out, void *stream) {
     const size_t ms = (size_t)M * nsample;
-    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, nullptr, idx, out,
+    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, C, nullptr, idx, out,
                         out ? out + 3 * ms : nullptr, stream, "query_group_stack_fwd: launch failed");
 }
 
 QG_API int mgar_query_group_stack_bwd(int B, int M, int C, int nsample, const float *grad_out, const int *idx,
                                       const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_features, void *stream) {
     return qg_stack_bwd(B, M, C, nsample, grad_out ? grad_out + 3 * (size_t)M * nsample : nullptr, idx, new_xyz_batch_cnt,
-                        xyz_batch_cnt, grad_features, stream, "query_group_stack_bwd: launch failed");
+                        xyz_batch_cnt, grad_features, C, stream, "query_group_stack_bwd: launch failed");
 }
 
 QG_API int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
-                                           const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, const float *wx,
-                                           const int *idx, float *rel_out, float *y_out, void *stream) {
-    MGAR_REQUIRE(wx && zf && y_out, "query_group_proj_stack_fwd: null pointer");
-    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx, idx, rel_out, y_out, stream,
-                        "query_group_proj_stack_fwd: launch failed");
+                                           const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, int zf_ld,
+                                           const float *wx, const int *idx, float *rel_out, float *y_out, void *stream) {
+    MGAR_REQUIRE(wx && zf && y_out && zf_ld >= C, "query_group_proj_stack_fwd: null pointer or zf_ld < C");
+    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, zf_ld, wx, idx, rel_out, y_out,
+                        stream, "query_group_proj_stack_fwd: launch failed");
 }
 
 QG_API int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
-                                           const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf, void *stream) {
-    return qg_stack_bwd(B, M, C, nsample, grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, stream,
+                                           const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf, int zf_ld,
+                                           void *stream) {
+    return qg_stack_bwd(B, M, C, nsample, grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, zf_ld, stream,
                         "query_group_proj_stack_bwd: launch failed");
 }

@@ -62,11 +62,21 @@ class StackSAModuleMSG(nn.Module):
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
         """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1]))."""
         per_scale = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            if (self.pool_method == 'max_pool' and features is not None and xyz.is_cuda and grouper.use_xyz
-                    and mlp.first_layer_foldable(3 + features.shape[1])):
-                # "project, then group": layer 0 is linear, apply its feature half to the N points first
-                y0, _ = grouper.forward_projected(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, mlp[0].weight)
+        projected = {}
+        if self.pool_method == 'max_pool' and features is not None and xyz.is_cuda:
+            # "project, then group": layer 0 is linear, apply its feature half to the N points first --
+            # for all scales in ONE GEMM over the shared features
+            fold = [k for k, (g, mlp) in enumerate(zip(self.groupers, self.mlps))
+                    if g.use_xyz and mlp.first_layer_foldable(3 + features.shape[1])]
+            if fold:
+                ys = pointnet2_utils._FusedQueryGroupProjMSG.apply(
+                    xyz, xyz_batch_cnt.int(), new_xyz, new_xyz_batch_cnt.int(), features,
+                    tuple(self.groupers[k].radius for k in fold), tuple(self.groupers[k].nsample for k in fold),
+                    *[self.mlps[k][0].weight for k in fold])
+                projected = dict(zip(fold, ys))
+        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if k in projected:
+                y0 = projected[k]
                 x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1)
                 per_scale.append(x.squeeze(0).permute(1, 0))
                 continue

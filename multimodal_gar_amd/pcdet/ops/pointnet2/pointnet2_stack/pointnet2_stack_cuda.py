@@ -74,14 +74,30 @@ def query_group_grad_wrapper(B, M, C, nsample, grad_out, idx_raw, new_xyz_batch_
     return 1
 
 
-def query_group_proj_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx, idx_raw, rel_out, y_out):
+def query_group_proj_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx, idx_raw, rel_out, y_out,
+                             zf_ld=None, zf_col=0):
+    """zf: (N, zf_ld) matrix whose columns zf_col .. zf_col + C hold this scale's projection."""
+    zf_ld = C if zf_ld is None else zf_ld
     L.call("mgar_query_group_proj_stack_fwd", B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
-           L.iptr(new_xyz_batch_cnt), L.fptr(zf), L.fptr(wx), L.iptr(idx_raw),
+           L.iptr(new_xyz_batch_cnt), zf.data_ptr() + 4 * zf_col, zf_ld, L.fptr(wx), L.iptr(idx_raw),
            L.fptr(rel_out) if rel_out is not None else None, L.fptr(y_out), L.stream_of(xyz))
     return 1
 
 
-def query_group_proj_grad_wrapper(B, M, C, nsample, grad_y, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf):
+def query_group_proj_grad_wrapper(B, M, C, nsample, grad_y, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, zf_ld=None,
+                                  zf_col=0):
+    zf_ld = C if zf_ld is None else zf_ld
     L.call("mgar_query_group_proj_stack_bwd", B, M, C, nsample, L.fptr(grad_y), L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt),
-           L.iptr(xyz_batch_cnt), L.fptr(grad_zf), L.stream_of(grad_y))
+           L.iptr(xyz_batch_cnt), grad_zf.data_ptr() + 4 * zf_col, zf_ld, L.stream_of(grad_y))
     return 1
+
+
+def rowmajor_dw(a, f):
+    """a (N, Co), f (N, Ci) row-major contiguous -> a^T f (Co, Ci) on csrc/rowmajor_dw.hip."""
+    import torch
+    n, co = a.shape
+    ci = f.shape[1]
+    dw = torch.empty((co, ci), dtype=torch.float32, device=a.device)
+    ws = torch.empty((max(1, L.raw("mgar_rowmajor_dw_workspace_floats", n, co, ci)),), dtype=torch.float32, device=a.device)
+    L.call("mgar_rowmajor_dw", L.fptr(a), co, L.fptr(f), ci, n, co, ci, L.fptr(ws), L.fptr(dw), L.stream_of(a))
+    return dw

@@ -152,6 +152,73 @@ class _FusedQueryGroupProj(Function):
         return None, None, None, None, None, None, grad_zf, grad_wx
 
 
+class _FusedQueryGroupProjMSG(Function):
+    """Multi-scale "project, then group": the scales of one StackSAModuleMSG share the source
+    features, so their first-layer projections are ONE GEMM zf = features @ [W_f,1; W_f,2; ...]^T
+    (N, sum C_k) -- one pass over the features instead of one per scale, and one pass for each of the
+    two gradients.  Per scale k: ball query + y_k = gather(zf[:, cols_k]) + wx_k . rel_xyz
+    (csrc/query_group.hip, zf read with leading dimension sum C_k).  The weight gradient
+    d W_f = grad_zf^T features runs on csrc/rowmajor_dw.hip.
+
+    apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, *weights)
+    with weights[k] (C_k, 3 + C) -> (y_1, ..., y_K), y_k (C_k, M * nsample_k) channel-major."""
+
+    @staticmethod
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, *weights):
+        n_samples, n_query = xyz_batch_cnt.shape[0], new_xyz.shape[0]
+        features = features.contiguous()
+        ws = [w.reshape(w.shape[0], -1) for w in weights]
+        chans = [w.shape[0] for w in ws]
+        ld = sum(chans)
+        w_f = torch.cat([w[:, 3:] for w in ws], 0).contiguous()                                # (ld, C)
+        zf = features @ w_f.t()                                                                # (N, ld)
+        outs, saved = [], []
+        col = 0
+        for radius, nsample, w, c in zip(radii, nsamples, ws, chans):
+            idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
+            pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+            wx = w[:, :3].contiguous()
+            rel = _empty(xyz, (3, n_query * nsample), torch.float32)
+            y = _empty(xyz, (c, n_query * nsample), torch.float32)
+            pointnet2.query_group_proj_wrapper(n_samples, n_query, c, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
+                                               zf, wx, idx, rel, y, zf_ld=ld, zf_col=col)
+            outs.append(y)
+            saved += [idx, rel]
+            col += c
+        ctx.save_for_backward(xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, *saved)
+        ctx.meta = (n_samples, n_query, tuple(chans), tuple(nsamples), tuple(w.shape for w in weights))
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grad_ys):
+        from .....nn_utils import pointwise_dw
+        xyz_batch_cnt, new_xyz_batch_cnt, features, w_f = ctx.saved_tensors[:4]
+        saved = ctx.saved_tensors[4:]
+        n_samples, n_query, chans, nsamples, w_shapes = ctx.meta
+        ld = sum(chans)
+        grad_zf = torch.zeros((features.shape[0], ld), dtype=torch.float32, device=features.device)
+        grad_wx = []
+        col = 0
+        for k, (c, nsample) in enumerate(zip(chans, nsamples)):
+            idx, rel = saved[2 * k], saved[2 * k + 1]
+            gy = grad_ys[k].contiguous()
+            pointnet2.query_group_proj_grad_wrapper(n_samples, n_query, c, nsample, gy, idx, new_xyz_batch_cnt, xyz_batch_cnt,
+                                                    grad_zf, zf_ld=ld, zf_col=col)
+            grad_wx.append(pointwise_dw(rel.unsqueeze(0), gy.unsqueeze(0)))                    # (C_k, 3)
+            col += c
+        grad_features = grad_zf @ w_f if ctx.needs_input_grad[4] else None
+        if ld <= 96 and features.shape[1] <= 128:
+            grad_wf = pointnet2.rowmajor_dw(grad_zf, features)                                 # (ld, C)
+        else:
+            grad_wf = grad_zf.t() @ features
+        grad_ws, col = [], 0
+        for c, gwx, shape in zip(chans, grad_wx, w_shapes):
+            grad_ws.append(torch.cat([gwx, grad_wf[col:col + c]], 1).view(shape))
+            col += c
+        return (None, None, None, None, grad_features, None, None, *grad_ws)
+
+
 class QueryAndGroup(nn.Module):
     """Returns (new_features (M, 3 + C, nsample), idx).  Relative xyz and features of empty
     balls are zeroed.  Reference: pointnet2_utils.py:112-159."""

@@ -344,6 +344,22 @@ def test_shared_mlp_fused_bn_conv_matches_unfused(chans, shape):
         close(bn_f.running_mean, bn_p.running_mean); close(bn_f.running_var, bn_p.running_var)
 
 
+@pytest.mark.parametrize("N,Co,Ci", [(100000, 96, 128), (4097, 32, 128), (513, 96, 99), (15, 7, 5), (250000, 64, 35)])
+def test_rowmajor_dw_matches_fp64(N, Co, Ci):
+    """a^T f for stacked (row-major) operands on the fp32 MFMA (csrc/rowmajor_dw.hip), incl. leading dimensions."""
+    from multimodal_gar_amd import _lib as L
+    torch.manual_seed(N % 97)
+    lda, ldf = Co + 5, Ci + 3
+    a = torch.randn(N, lda, device="cuda"); f = torch.randn(N, ldf, device="cuda")
+    dw = torch.full((Co, Ci), float("nan"), device="cuda")
+    ws = torch.empty(L.raw("mgar_rowmajor_dw_workspace_floats", N, Co, Ci), device="cuda")
+    L.call("mgar_rowmajor_dw", L.fptr(a), lda, L.fptr(f), ldf, N, Co, Ci, L.fptr(ws), L.fptr(dw), L.stream_of(a))
+    close(dw, a[:, :Co].double().t() @ f[:, :Ci].double(), rtol=2e-5, atol=1e-3)
+    dw2 = torch.empty_like(dw)
+    L.call("mgar_rowmajor_dw", L.fptr(a), lda, L.fptr(f), ldf, N, Co, Ci, L.fptr(ws), L.fptr(dw2), L.stream_of(a))
+    assert torch.equal(dw, dw2)
+
+
 def test_conv1x1_uses_dw_kernel_and_matches_torch_conv():
     from multimodal_gar_amd.nn_utils import conv1x1
     torch.manual_seed(9)
