@@ -7,9 +7,13 @@
 // On ROCm the pad is a strided-copy kernel over the whole activation and the pooling kernel
 // (max_pool3d_with_indices_single_out_frame) also produces an index tensor nobody reads: 21 ms +
 // ~10 ms per c3 step.  I3D is frozen in MGAR-net (I3D_FREEZE), so only the forward is needed.
-// One thread per output element, w fastest; the window is read straight from the un-padded input
-// (rows stay in L1/L2), and "the window touches the zero padding" is folded in as max(., 0).
-// HBM-bound: input read once, output written once.
+// The window is read straight from the un-padded input (rows stay in L1/L2), and "the window
+// touches the zero padding" is folded in as max(., 0).  HBM-bound: input read once, output written
+// once.  Main kernel: one thread per FOUR consecutive outputs of a row; per input row of the window
+// it loads one aligned 16-byte vector (two for stride 2) plus the one or two edge elements and
+// forms the four horizontal maxima in registers -- 3 loads per row and 4 outputs instead of 12 --
+// and writes a float4; (t, nc) come from the grid, so there is no 64-bit index arithmetic.  A
+// one-thread-per-output kernel covers the other geometries.
 #include "common.hpp"
 
 namespace mgar {
@@ -41,6 +45,53 @@ __global__ __launch_bounds__(256) void maxpool3d_same_kernel(const float *__rest
     }
 }
 
+// kw == 3 and (SW == 1, front pad 1) or (SW == 2, front pad 0); W % 4 == 0, Wo % 4 == 0.
+// grid (ceil(Ho * Wo/4 / 256), To, NC)
+template <int SW>
+__global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__restrict__ x, Pool3dGeom g, float *__restrict__ y) {
+    const int nq = g.Wo >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int ho = q / nq, wq = q - ho * nq;
+    if (ho >= g.Ho) return;
+    const int to = blockIdx.y;
+    const size_t nc = blockIdx.z;
+    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph;
+    const int t1 = t0 + g.kt, h1 = h0 + g.kh;
+    const bool pad_th = t0 < 0 || h0 < 0 || t1 > g.T || h1 > g.H;
+    const float ninf = -__builtin_inff();
+    float b0 = ninf, b1 = ninf, b2 = ninf, b3 = ninf;
+    const float *base = x + nc * g.T * g.H * g.W;
+    const int wb = wq * 4 * SW;  // first aligned input column of this quad
+    for (int t = max(t0, 0); t < min(t1, g.T); ++t)
+        for (int h = max(h0, 0); h < min(h1, g.H); ++h) {
+            const float *row = base + ((size_t)t * g.H + h) * g.W + wb;
+            if (SW == 1) {  // outputs j = 0..3 cover inputs wb + j - 1 .. wb + j + 1
+                const float4 v = *reinterpret_cast<const float4 *>(row);
+                const float lft = wb > 0 ? row[-1] : ninf;
+                const float rgt = wb + 4 < g.W ? row[4] : ninf;
+                b0 = fmaxf(b0, fmaxf(fmaxf(lft, v.x), v.y));
+                b1 = fmaxf(b1, fmaxf(fmaxf(v.x, v.y), v.z));
+                b2 = fmaxf(b2, fmaxf(fmaxf(v.y, v.z), v.w));
+                b3 = fmaxf(b3, fmaxf(fmaxf(v.z, v.w), rgt));
+            } else {        // outputs j cover inputs wb + 2j .. wb + 2j + 2
+                const float4 v = *reinterpret_cast<const float4 *>(row);
+                const float4 u = *reinterpret_cast<const float4 *>(row + 4);
+                const float rgt = wb + 8 < g.W ? row[8] : ninf;
+                b0 = fmaxf(b0, fmaxf(fmaxf(v.x, v.y), v.z));
+                b1 = fmaxf(b1, fmaxf(fmaxf(v.z, v.w), u.x));
+                b2 = fmaxf(b2, fmaxf(fmaxf(u.x, u.y), u.z));
+                b3 = fmaxf(b3, fmaxf(fmaxf(u.z, u.w), rgt));
+            }
+        }
+    // zero padding takes part in the max wherever the window leaves the input
+    const bool pad_l = SW == 1 && wb == 0;
+    const bool pad_r = SW == 1 ? (wb + 4 >= g.W) : (wb + 8 >= g.W);
+    if (pad_th || pad_l) b0 = fmaxf(b0, 0.f);
+    if (pad_th) { b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); }
+    if (pad_th || pad_r) b3 = fmaxf(b3, 0.f);
+    *reinterpret_cast<float4 *>(y + ((nc * g.To + to) * g.Ho + ho) * g.Wo + wq * 4) = make_float4(b0, b1, b2, b3);
+}
+
 }  // namespace mgar
 
 using namespace mgar;
@@ -58,6 +109,13 @@ extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd(co
     };
     Pool3dGeom g{T, H, W, (T + st - 1) / st, (H + sh - 1) / sh, (W + sw - 1) / sw, kt, kh, kw, st, sh, sw,
                  front(T, kt, st), front(H, kh, sh), front(W, kw, sw)};
+    const bool vec1 = kw == 3 && sw == 1 && g.pw == 1, vec2 = kw == 3 && sw == 2 && g.pw == 0 && W % 2 == 0;
+    if ((vec1 || vec2) && W % 4 == 0 && g.Wo % 4 == 0 && g.To <= 65535 && NC <= 65535 && (!vec2 || W >= 8)) {
+        dim3 grid(ceil_div(g.Ho * (g.Wo / 4), 256), g.To, NC);
+        if (vec1) hipLaunchKernelGGL(maxpool3d_same_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
+        else hipLaunchKernelGGL(maxpool3d_same_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
+        return check_launch("maxpool3d_same_fwd: launch failed");
+    }
     const long long total = (long long)NC * g.To * g.Ho * g.Wo;
     const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     hipLaunchKernelGGL(maxpool3d_same_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, total, g, y);

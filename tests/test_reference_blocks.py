@@ -150,7 +150,11 @@ def test_i3d_on_device_matches_reference_golden():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,k,s", [((2, 5, 15, 33, 47), (3, 3, 3), (2, 2, 2)), ((1, 7, 8, 20, 31), (1, 3, 3), (1, 2, 2)),
-                                       ((2, 3, 4, 9, 10), (3, 3, 3), (1, 1, 1)), ((1, 2, 5, 6, 7), (2, 2, 2), (2, 2, 2))])
+                                       ((2, 3, 4, 9, 10), (3, 3, 3), (1, 1, 1)), ((1, 2, 5, 6, 7), (2, 2, 2), (2, 2, 2)),
+                                       # the vectorised kernel: W % 4 == 0 (stride 1) / W % 8 == 0 (stride 2)
+                                       ((2, 3, 4, 9, 12), (3, 3, 3), (1, 1, 1)), ((1, 5, 3, 7, 160), (3, 3, 3), (1, 1, 1)),
+                                       ((1, 4, 8, 22, 48), (1, 3, 3), (1, 2, 2)), ((2, 3, 7, 13, 16), (3, 3, 3), (2, 2, 2)),
+                                       ((1, 2, 1, 1, 4), (3, 3, 3), (1, 1, 1)), ((1, 2, 2, 3, 8), (1, 3, 3), (1, 2, 2))])
 def test_maxpool3d_same_padding_kernel(shape, k, s):
     from multimodal_gar_amd.model.backbone import MaxPool3dSamePadding
     torch.manual_seed(0)
