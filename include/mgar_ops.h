@@ -213,14 +213,16 @@ int mgar_rowmajor_dw(const float *a, int lda, const float *f, int ldf, long long
  * Activations are x (B, C, P) contiguous, P = npoint*nsample columns.
  * workspace: caller-allocated floats, mgar_bn_workspace_floats(B, C, P) of them.
  *   train_stats : per-channel mean / invstd = 1/sqrt(var_biased + eps) of x; if running_* are
- *                 non-NULL they receive the usual momentum update (unbiased variance).
+ *                 non-NULL they receive the usual momentum update (unbiased variance) and the int64
+ *                 counter num_batches_tracked (may be NULL) is incremented.
  *   act_fwd     : y = [relu](x * gamma*invstd + beta - mean*gamma*invstd)   (gamma/beta may be NULL)
  *   act_maxpool_fwd : out (B,C,M) = max_s [relu](bn(x[b,c,m,s])), arg (B,C,M) uint8 = first arg-max
  *   act_bwd     : dx, dgamma, dbeta of y = [relu](bn_train(x)) given dy (all fully written)
  *   act_maxpool_bwd : the same when y was reduced by act_maxpool_fwd (dpool, pooled, arg) */
 int mgar_bn_workspace_floats(int B, int C, int P);
 int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace,
-                        float *mean, float *invstd, float *running_mean, float *running_var, void *stream);
+                        float *mean, float *invstd, float *running_mean, float *running_var,
+                        long long *num_batches_tracked, void *stream);
 int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean,

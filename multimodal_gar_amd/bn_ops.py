@@ -26,9 +26,9 @@ def _train_stats(x3, bn):
     ws = _workspace(x3, b, c, p)
     L.call("mgar_bn_train_stats", L.fptr(x3), b, c, p, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
            L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
-           L.fptr(bn.running_var) if track else None, L.stream_of(x3))
-    if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+           L.fptr(bn.running_var) if track else None,
+           L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
+           L.stream_of(x3))
     return mean, invstd
 
 

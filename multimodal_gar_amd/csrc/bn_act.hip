@@ -24,7 +24,7 @@
 namespace mgar {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_CHUNK = 65536;  // elements of one channel reduced by one workgroup
+constexpr int BN_CHUNK = 65536;  // most elements of one channel reduced by one workgroup (bn_chunk() shrinks it for small inputs)
 
 __device__ __forceinline__ float block_sum(float v, float *scratch) {
     v = wave_sum(v);
@@ -45,15 +45,16 @@ __device__ __forceinline__ size_t chan_off(long long e, int c, int C, int P) {
 
 // ---- statistics: 4 B read per element -------------------------------------------------------
 // grid (nchunk, C).  partial[(c * nchunk + chunk) * 2 + {0,1}] = sum, sum of squares
-__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__restrict__ x, int B, int C, int P,
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__restrict__ x, int B, int C, int P, int chunk,
                                                                 float *__restrict__ partial) {
     __shared__ float scratch[BN_THREADS / 64];
     const int c = blockIdx.y;
     const long long n = (long long)B * P;
-    const long long e0 = (long long)blockIdx.x * BN_CHUNK;
-    const long long e1 = min(e0 + BN_CHUNK, n);
+    const long long e0 = (long long)blockIdx.x * chunk;
+    const long long e1 = min(e0 + chunk, n);
     float s = 0.f, q = 0.f;
     if ((P & 3) == 0) {
+#pragma unroll 4
         for (long long e = e0 + (long long)threadIdx.x * 4; e < e1; e += BN_THREADS * 4) {
             const float4 v = *reinterpret_cast<const float4 *>(x + chan_off(e, c, C, P));
             s += (v.x + v.y) + (v.z + v.w);
@@ -74,17 +75,26 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__r
     }
 }
 
-// one thread per channel: combine the chunk sums in double, write mean / invstd, update running stats
-__global__ void bn_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float eps, float momentum,
-                                   float *__restrict__ mean, float *__restrict__ invstd, float *__restrict__ running_mean,
-                                   float *__restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per channel: combine the chunk sums in double (lanes stride over the chunks, then a
+// fixed-order shuffle tree), write mean / invstd, update running stats
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float eps,
+                                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
+                                                         float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                         long long *__restrict__ num_batches_tracked) {
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < nchunk; ++i) {
+    for (int i = threadIdx.x; i < nchunk; i += 64) {
         s += (double)partial[((size_t)c * nchunk + i) * 2 + 0];
         q += (double)partial[((size_t)c * nchunk + i) * 2 + 1];
     }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (threadIdx.x != 0) return;
     const double m = s / n;
     double var = q / n - m * m;
     if (var < 0.0) var = 0.0;
@@ -92,6 +102,7 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partial, int nchunk
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+    if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
 }
 
 // ---- apply: 4 B read + 4 B written per element ----------------------------------------------
@@ -277,16 +288,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const fl
     }
 }
 
-// d_beta[c] (+)= sum dz ; d_gamma[c] (+)= sum dz*xhat ; coef[c] = {mean dz, mean dz*xhat}
-__global__ void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float *__restrict__ dgamma,
-                                       float *__restrict__ dbeta, float *__restrict__ coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// d_beta[c] = sum dz ; d_gamma[c] = sum dz*xhat ; coef[c] = {mean dz, mean dz*xhat}.  One wave per channel.
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                             float *__restrict__ coef) {
+    const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
-    for (int i = 0; i < nchunk; ++i) {
+    for (int i = threadIdx.x; i < nchunk; i += 64) {
         s += (double)partial[((size_t)c * nchunk + i) * 2 + 0];
         q += (double)partial[((size_t)c * nchunk + i) * 2 + 1];
     }
+    s = wave_sum_f64(s);
+    q = wave_sum_f64(q);
+    if (threadIdx.x != 0) return;
     if (dbeta) dbeta[c] = (float)s;
     if (dgamma) dgamma[c] = (float)q;
     coef[2 * c + 0] = (float)(s / n);
@@ -366,6 +380,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const floa
     }
 }
 
+// chunk of the FORWARD statistics pass: shrink it until ~2048 workgroups exist (the I3D layers of a
+// single clip have as few as 14 400 elements per channel)
+static inline int bn_chunk(int B, int C, long long P) {
+    const long long n = (long long)B * P;
+    int chunk = BN_CHUNK;
+    while (chunk > 4096 && ((n + chunk - 1) / chunk) * C < 2048) chunk >>= 1;
+    return chunk;
+}
+static inline int bn_nchunk_fwd(int B, int C, long long P) {
+    const int chunk = bn_chunk(B, C, P);
+    return (int)(((long long)B * P + chunk - 1) / chunk);
+}
 static inline int bn_nchunk(int B, int P) { return (int)(((long long)B * P + BN_CHUNK - 1) / BN_CHUNK); }
 
 }  // namespace mgar
@@ -376,22 +402,24 @@ using namespace mgar;
 
 BN_API int mgar_bn_workspace_floats(int B, int C, int P) {
     if (B < 0 || C < 0 || P < 0) return MGAR_EINVAL;
-    return 2 * C * (bn_nchunk(B, P) > 0 ? bn_nchunk(B, P) : 1) + 2 * C;
+    const int nc = bn_nchunk_fwd(B, C, P) > bn_nchunk(B, P) ? bn_nchunk_fwd(B, C, P) : bn_nchunk(B, P);
+    return 2 * C * (nc > 0 ? nc : 1) + 2 * C;
 }
 
 static int bn_sizes_ok(int B, int C, long long P) { return B >= 0 && C >= 0 && P >= 0 && (long long)B * C <= 2147483647LL; }
 
 BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean,
-                               float *invstd, float *running_mean, float *running_var, void *stream) {
+                               float *invstd, float *running_mean, float *running_var, long long *num_batches_tracked,
+                               void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_train_stats: bad sizes");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(x && workspace && mean && invstd, "bn_train_stats: null pointer");
     MGAR_REQUIRE(C <= 65535, "bn_train_stats: C > 65535");
-    const int nchunk = bn_nchunk(B, P);
+    const int chunk = bn_chunk(B, C, P), nchunk = bn_nchunk_fwd(B, C, P);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, workspace);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, eps,
-                       momentum, mean, invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, chunk, workspace);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, eps,
+                       momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
     return check_launch("bn_train_stats: launch failed");
 }
 
@@ -448,7 +476,7 @@ BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P,
     hipStream_t st = (hipStream_t)stream;
     if (relu) hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
     if (relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
@@ -468,7 +496,7 @@ BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, cons
     if (relu) hipLaunchKernelGGL(bn_max_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
     else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)));
     if (relu) hipLaunchKernelGGL(bn_max_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
     else hipLaunchKernelGGL(bn_max_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);

@@ -342,6 +342,7 @@ def test_shared_mlp_fused_bn_conv_matches_unfused(chans, shape):
             close(a, b, rtol=5e-4)
     for bn_f, bn_p in zip([m for m in mlp if hasattr(m, "running_mean")], [m for m in plain if hasattr(m, "running_mean")]):
         close(bn_f.running_mean, bn_p.running_mean); close(bn_f.running_var, bn_p.running_var)
+        assert int(bn_f.num_batches_tracked) == 1 and int(bn_p.num_batches_tracked) == 1     # counted inside the stats kernel
 
 
 @pytest.mark.parametrize("N,Co,Ci", [(100000, 96, 128), (4097, 32, 128), (513, 96, 99), (15, 7, 5), (250000, 64, 35)])
