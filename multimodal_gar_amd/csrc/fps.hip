@@ -174,10 +174,13 @@ __global__ __launch_bounds__(T) void fps_kernel(FpsArgs A) {
         // ---- per-lane scan in ascending priority, strict '>' keeps the first maximum ----
         float best = -1.f;
         int bslot = 0;
+        // whole-vector arithmetic: the backend pairs the lanes of the register arrays into
+        // v_pk_add/mul/fma_f32 (2 points per instruction); same operations, same rounding as d2_of
+        const typename VecOf<PPT>::f dx = X - x1, dy = Y - y1, dz = Z - z1;
+        const typename VecOf<PPT>::f dd = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dx, dx, dy * dy));
 #pragma unroll
         for (int s = 0; s < PPT; ++s) {
-            const float d = d2_of(X[s] - x1, Y[s] - y1, Z[s] - z1);
-            const float d2 = vmin(d, D[s]);
+            const float d2 = vmin(dd[s], D[s]);
             D[s] = d2;
             bslot = d2 > best ? s : bslot;
             best = vmax(best, d2);
