@@ -52,55 +52,47 @@ def parse():
 
 
 # --------------------------------------------------------------------------------------------
-# Live timing of the hand-written kernels at the workload's shapes (events on the current stream,
-# which is the stream the C ABI launches on).
+# Live timing of the hand-written kernels: the library brackets each instrumented kernel launch with
+# two HIP events recorded on the stream the kernel is launched on (csrc/errors.hip, mgar_ktimer_*) and
+# notes the launch's algorithmic bytes / flops.  The timers
+# are switched on for ONE extra step of the same workload right after the timed region, so the headline
+# number is not perturbed by ~3 000 event records per step.
 # --------------------------------------------------------------------------------------------
-def time_kernel(fn, iters=5):
-    fn(); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
+MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel")
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # rocprofv3 --pmc passes, see profiles/README.md
+
+
+def kernel_rooflines(step, batch, frames, n_points):
+    """-> list of per-kernel roofline dicts for one training step, the dominant (largest total time) first."""
+    from multimodal_gar_amd import _lib as L
+    L.kernel_timers(enable=True)
+    L.kernel_timers()                       # drop anything recorded so far
+    step.run(batch)
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters  # ms
-
-
-def kernel_rooflines(points, frames_per_rank, n_points):
-    """Times FPS / ball query / three_nn (the O(M*N) scans) at level-1 shapes of this rank's batch.
-    Returns a list of roofline dicts, the dominant (longest per step) first."""
-    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pb
-    xyz = points[..., :3].contiguous()
-    f, n = xyz.shape[0], xyz.shape[1]
-    m = n // 4
+    L.kernel_timers(enable=False)
+    table = L.kernel_timers()
+    traffic = {}
+    if os.path.exists(PMC_TRAFFIC_FILE):
+        try:
+            traffic = json.load(open(PMC_TRAFFIC_FILE)).get("per_launch_bytes", {})
+        except (OSError, ValueError):
+            traffic = {}
     res = []
-    # FPS: algorithmic bytes 12N + 4N(temp in) + 4N(temp out) + 4M per cloud; bound by the serial
-    # VALU chain, so also report pair evaluations / s (10 VALU per pair, DESIGN.md)
-    t = time_kernel(lambda: pb.farthest_point_sample(xyz, m), iters=3)
-    by = f * (12 * n + 8 * n + 4 * m)
-    pairs = f * (m - 1) * n
-    res.append({"kernel": "fps_kernel<1024,%d> (N=%d -> M=%d, %d clouds)" % (max(n // 1024, 1), n, m, f), "ms": t,
-                "bound": "hbm", "achieved": by / t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": by / t / 1e6 / HBM_PEAK_GBS, "traffic": None,
-                "pair_evals_per_s": pairs / (t * 1e-3), "valu_frac": pairs * 10 * 2 / (t * 1e-3) / 1e12 / VALU_PEAK_TFLOPS,
-                "per_step_launches": 1})
-    idx = pb.farthest_point_sample(xyz, m)
-    new_xyz = torch.gather(xyz, 1, idx.long()[..., None].expand(-1, -1, 3)).contiguous()
-    for radius, ns in ((0.1, 16), (0.5, 32)):
-        t = time_kernel(lambda: pb.ball_query(radius, ns, xyz, new_xyz))
-        by = f * (12 * n + 12 * m + 4 * m * ns)
-        pairs = f * m * n
-        res.append({"kernel": "ball_query_kernel<batch> (r=%.1f, ns=%d, M=%d x N=%d, %d clouds)" % (radius, ns, m, n, f),
-                    "ms": t, "bound": "hbm", "achieved": by / t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": by / t / 1e6 / HBM_PEAK_GBS, "traffic": None, "pair_evals_per_s": pairs / (t * 1e-3),
-                    "valu_frac": pairs * 7 * 2 / (t * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, "per_step_launches": 1})
-    t = time_kernel(lambda: pb.three_nn(xyz, new_xyz))
-    by = f * (12 * n + 12 * m + 24 * n)
-    res.append({"kernel": "three_nn_kernel<batch> (n=%d x m=%d, %d clouds)" % (n, m, f), "ms": t, "bound": "hbm",
-                "achieved": by / t / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / t / 1e6 / HBM_PEAK_GBS,
-                "traffic": None, "pair_evals_per_s": f * n * m / (t * 1e-3),
-                "valu_frac": f * n * m * 8 * 2 / (t * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, "per_step_launches": 1})
-    res.sort(key=lambda r: -r["ms"])
+    for name, (ms, launches, nbytes, flops) in table.items():
+        gbs = nbytes / ms / 1e6 if ms > 0 else 0.0
+        row = {"kernel": name, "launches_per_step": launches, "ms_per_step": ms, "avg_launch_ms": ms / launches,
+               "algorithmic_bytes_per_launch": nbytes / launches, "traffic": traffic.get(name)}
+        if name in MFMA_KERNELS:
+            tf = flops / ms / 1e9 if ms > 0 else 0.0
+            row.update({"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
+                        "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+        else:
+            row.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+        if name == "fps_kernel" and flops:
+            row["pair_evals_per_s"] = flops / 8.0 / (ms * 1e-3)       # 8 flop per pair evaluation
+            row["valu_frac"] = flops / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS
+        res.append(row)
+    res.sort(key=lambda r: -r["ms_per_step"])
     return res
 
 
@@ -228,9 +220,16 @@ def main():
     value = args.clips * args.steps / elapsed
 
     roof, kernels, cpu = None, None, None
-    if rank == 0 and not args.no_kernel_timing:
-        kernels = kernel_rooflines(batch["points"], clips_local * args.frames, args.points)
-        roof = dict(kernels[0])
+    if not args.no_kernel_timing:
+        if rank == 0:
+            kernels = kernel_rooflines(step, batch, clips_local * args.frames, args.points)
+            roof = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step",
+                                               "ms_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch")}
+            log("dominant hand-written kernel: %s, %.2f ms/step in %d launches, %.0f %s (%.1f %% of peak)"
+                % (roof["kernel"], roof["ms_per_step"], roof["launches_per_step"], roof["achieved"], roof["unit"], 100 * roof["frac"]))
+        else:
+            step.run(batch)          # the extra (instrumented on rank 0) step is collective under DDP
+        barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
     if rank == 0:

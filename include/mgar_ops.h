@@ -37,6 +37,16 @@ extern "C" {
 int mgar_abi_version(void);
 const char *mgar_last_error(void);
 
+/* Optional per-kernel timing for roofline reports (bench.py): while enabled, each instrumented
+ * launcher brackets its main kernel with two HIP events on the launch stream and notes the launch's
+ * algorithmic bytes / flops.  mgar_ktimer_read waits for the events of kernel
+ * `id` (0 <= id < mgar_ktimer_count()) and returns totals since the last reset. */
+int mgar_ktimer_enable(int on);
+int mgar_ktimer_count(void);
+const char *mgar_ktimer_name(int id);
+int mgar_ktimer_read(int id, double *total_ms, long long *launches, double *total_bytes, double *total_flops,
+                     int reset);
+
 /* ======================= pointnet2_batch: (B, N, 3) / (B, C, N) ======================= */
 
 /* ball_query_wrapper   pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:11

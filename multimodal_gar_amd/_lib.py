@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -50,6 +50,9 @@ _PROTOS = {
     "mgar_query_group_proj_stack_fwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_query_group_proj_stack_bwd": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P],
     "mgar_rowmajor_dw_workspace_floats": [_LL, _I, _I],
+    "mgar_ktimer_enable": [_I],
+    "mgar_ktimer_count": [],
+    "mgar_ktimer_read": [_I, _P, _P, _P, _P, _I],
     "mgar_rowmajor_dw": [_P, _I, _P, _I, _LL, _I, _I, _P, _P, _P],
     "mgar_bn_workspace_floats": [_I, _I, _I],
     "mgar_bn_train_stats": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
@@ -124,5 +127,22 @@ def call(name, *args):
     return rc
 
 
+def kernel_timers(enable=None, reset=True):
+    """enable=True/False switches the per-kernel HIP-event timers of the library; otherwise returns
+    {kernel name: (total_ms, launches, algorithmic_bytes, flops)} since the last reset."""
+    if enable is not None:
+        call("mgar_ktimer_enable", int(bool(enable)))
+        return None
+    _cdll.mgar_ktimer_name.restype = ctypes.c_char_p
+    _cdll.mgar_ktimer_name.argtypes = [ctypes.c_int]
+    out = {}
+    for i in range(raw("mgar_ktimer_count")):
+        ms, by, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_longlong()
+        call("mgar_ktimer_read", i, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(by), ctypes.byref(fl), int(reset))
+        if n.value:
+            out[_cdll.mgar_ktimer_name(i).decode()] = (ms.value, n.value, by.value, fl.value)
+    return out
+
+
 def exported_symbols():
-    return sorted(_PROTOS) + ["mgar_abi_version", "mgar_last_error"]
+    return sorted(_PROTOS) + ["mgar_abi_version", "mgar_last_error", "mgar_ktimer_name"]

@@ -155,6 +155,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_ball_query_batch(int 
     MGAR_REQUIRE(b <= 65535, "ball_query_batch: b > 65535");
     const size_t lds = (size_t)(nsample * BQ_ROW_STRIDE + BQ_THREADS) * sizeof(int);
     dim3 grid(ceil_div(m, BQ_THREADS), b);
+    KtScope kt(KT_BALL_QUERY, (hipStream_t)stream, (double)b * (12.0 * n + 12.0 * m + 4.0 * m * nsample));
     hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(BQ_THREADS), lds, (hipStream_t)stream, b, n, m,
                        radius * radius, nsample, new_xyz, (const int *)nullptr, xyz, (const int *)nullptr, idx);
     return check_launch("ball_query_batch: launch failed");
@@ -171,6 +172,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_ball_query_stack(int 
     // sum_i ceil(M_i/256) <= ceil(M/256) + B; surplus workgroups exit at once.  The counts
     // live on the device, so sizing the grid exactly would cost a host sync.
     dim3 grid(ceil_div(M, BQ_THREADS) + B);
+    KtScope kt(KT_BALL_QUERY, (hipStream_t)stream, 12.0 * M + 4.0 * (double)M * nsample);   // + 12 N: N lives on the device
     hipLaunchKernelGGL(ball_query_kernel<true>, grid, dim3(BQ_THREADS), lds, (hipStream_t)stream, B, 0, 0,
                        radius * radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx);
     return check_launch("ball_query_stack: launch failed");

@@ -417,7 +417,9 @@ BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, f
     MGAR_REQUIRE(C <= 65535, "bn_train_stats: C > 65535");
     const int chunk = bn_chunk(B, C, P), nchunk = bn_nchunk_fwd(B, C, P);
     hipStream_t st = (hipStream_t)stream;
+    { KtScope kt(KT_BN_STATS, st, 4.0 * (double)B * C * P);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, chunk, workspace);
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, eps,
                        momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
     return check_launch("bn_train_stats: launch failed");
@@ -431,8 +433,10 @@ BN_API int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mea
     MGAR_REQUIRE((long long)P <= 65535LL * BN_THREADS * 4, "bn_act_fwd: P too large");
     dim3 grid(B * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
     hipStream_t st = (hipStream_t)stream;
+    { KtScope kt(KT_BN_APPLY, st, 8.0 * (double)B * C * P);
     if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
     else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
+    }
     return check_launch("bn_act_fwd: launch failed");
 }
 
@@ -444,6 +448,7 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
     MGAR_REQUIRE(x && out && arg && mean && invstd, "bn_act_maxpool_fwd: null pointer");
     MGAR_REQUIRE((long long)M <= 65535LL * BN_THREADS, "bn_act_maxpool_fwd: M too large");
     hipStream_t st = (hipStream_t)stream;
+    KtScope kt(KT_BN_MAX, st, (double)B * C * M * (4.0 * nsample + 5.0));
 #define BN_MAX_VEC(G)                                                                                                  \
     {                                                                                                                  \
         dim3 gv(B * C, ceil_div((long long)M * (G), BN_THREADS));                                                      \
@@ -474,12 +479,16 @@ BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P,
     const int nchunk = bn_nchunk(B, P);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
+    { KtScope kt(KT_BN_BWD_REDUCE, st, 8.0 * (double)B * C * P);
     if (relu) hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
+    { KtScope kt(KT_BN_BWD_APPLY, st, 12.0 * (double)B * C * P);
     if (relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    }
     return check_launch("bn_act_bwd: launch failed");
 }
 
@@ -493,12 +502,16 @@ BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, cons
     const int nchunk = bn_nchunk(B, M);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
+    { KtScope kt(KT_BN_MAX_BWD_REDUCE, st, 13.0 * (double)B * C * M);
     if (relu) hipLaunchKernelGGL(bn_max_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
     else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
+    }
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)));
+    { KtScope kt(KT_BN_MAX_BWD_APPLY, st, (double)B * C * M * (8.0 * nsample + 9.0));
     if (relu) hipLaunchKernelGGL(bn_max_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
     else hipLaunchKernelGGL(bn_max_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
+    }
     return check_launch("bn_act_maxpool_bwd: launch failed");
 }

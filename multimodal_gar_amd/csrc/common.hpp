@@ -49,6 +49,27 @@ __device__ __forceinline__ float wave_max(float v) {
 
 void set_error(const char *msg);
 
+// ---- optional per-kernel timing (bench.py's roofline table) --------------------------------------
+// When switched on through mgar_ktimer_enable(), a launcher brackets ONE kernel launch with two HIP
+// events recorded on the launch stream and notes the launch's algorithmic bytes / flops
+// (SURVEY.md section 8d figures); mgar_ktimer_read() resolves the events.
+// Off by default: one predictable branch per launch.
+enum KernelId {
+    KT_FPS = 0, KT_BALL_QUERY, KT_THREE_NN, KT_THREE_INTERP_FWD, KT_THREE_INTERP_BWD, KT_QUERY_GROUP_FWD, KT_QUERY_GROUP_BWD,
+    KT_BN_STATS, KT_BN_APPLY, KT_BN_MAX, KT_BN_BWD_REDUCE, KT_BN_BWD_APPLY, KT_BN_MAX_BWD_REDUCE, KT_BN_MAX_BWD_APPLY,
+    KT_POINTWISE_FWD, KT_POINTWISE_DW, KT_ROWMAJOR_DW, KT_MAXPOOL3D, KT_COUNT
+};
+extern int g_kt_on;
+void kt_begin(int id, hipStream_t st);
+void kt_end(int id, hipStream_t st, double bytes, double flops);
+struct KtScope {  // RAII: events around the launches issued while it is alive
+    int id; hipStream_t st; double bytes, flops;
+    KtScope(int id_, hipStream_t st_, double bytes_, double flops_ = 0.0) : id(id_), st(st_), bytes(bytes_), flops(flops_) {
+        if (g_kt_on) kt_begin(id, st);
+    }
+    ~KtScope() { if (g_kt_on) kt_end(id, st, bytes, flops); }
+};
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -1,10 +1,84 @@
-// errors.hip -- per-thread last-error string and ABI version of libmgar_hip.so.
+// errors.hip -- per-thread last-error string, ABI version and the optional per-kernel timers of
+// libmgar_hip.so.
 #include "common.hpp"
+
+#include <mutex>
+#include <vector>
 
 namespace mgar {
 static thread_local const char *g_last_error = "";
 void set_error(const char *msg) { g_last_error = msg; }
+
+int g_kt_on = 0;
+namespace {
+struct KtLaunch { hipEvent_t a, b; };
+struct KtSlot {
+    std::vector<KtLaunch> pending;
+    hipEvent_t open = nullptr;
+    double ms = 0.0, bytes = 0.0, flops = 0.0;
+    long long launches = 0;
+};
+KtSlot g_kt[KT_COUNT];
+std::mutex g_kt_mu;
+const char *const kKtNames[KT_COUNT] = {
+    "fps_kernel", "ball_query_kernel", "three_nn_kernel", "three_interp_fwd", "three_interp_bwd", "query_group_fwd",
+    "query_group_bwd", "bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel",
+    "bn_bwd_apply_kernel", "bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel",
+    "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel"};
+}  // namespace
+
+void kt_begin(int id, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    KtSlot &s = g_kt[id];
+    if (hipEventCreate(&s.open) != hipSuccess) { s.open = nullptr; return; }
+    (void)hipEventRecord(s.open, st);
+}
+void kt_end(int id, hipStream_t st, double bytes, double flops) {
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    KtSlot &s = g_kt[id];
+    if (!s.open) return;
+    hipEvent_t b;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(s.open); s.open = nullptr; return; }
+    (void)hipEventRecord(b, st);
+    s.pending.push_back({s.open, b});
+    s.open = nullptr;
+    s.bytes += bytes;
+    s.flops += flops;
+    s.launches += 1;
+}
 }  // namespace mgar
 
-extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 1; }
+using namespace mgar;
+
+extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 2; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_last_error(void) { return mgar::g_last_error; }
+
+extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on) {
+    g_kt_on = on ? 1 : 0;
+    return MGAR_OK;
+}
+extern "C" __attribute__((visibility("default"))) int mgar_ktimer_count(void) { return KT_COUNT; }
+extern "C" __attribute__((visibility("default"))) const char *mgar_ktimer_name(int id) {
+    return id >= 0 && id < KT_COUNT ? kKtNames[id] : "";
+}
+// Waits for the recorded events of kernel `id`, adds their elapsed times, returns the totals since the
+// last reset (reset != 0 clears them afterwards).
+extern "C" __attribute__((visibility("default"))) int mgar_ktimer_read(int id, double *total_ms, long long *launches,
+                                                                      double *total_bytes, double *total_flops, int reset) {
+    MGAR_REQUIRE(id >= 0 && id < KT_COUNT, "ktimer_read: bad kernel id");
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    KtSlot &s = g_kt[id];
+    for (KtLaunch &l : s.pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(l.b) == hipSuccess && hipEventElapsedTime(&ms, l.a, l.b) == hipSuccess) s.ms += ms;
+        (void)hipEventDestroy(l.a);
+        (void)hipEventDestroy(l.b);
+    }
+    s.pending.clear();
+    if (total_ms) *total_ms = s.ms;
+    if (launches) *launches = s.launches;
+    if (total_bytes) *total_bytes = s.bytes;
+    if (total_flops) *total_flops = s.flops;
+    if (reset) { s.ms = s.bytes = s.flops = 0.0; s.launches = 0; }
+    return MGAR_OK;
+}

@@ -320,6 +320,9 @@ static int fps_dispatch(int nclouds, int n_max, int bs_log2, const FpsArgs &A, h
     const int T = bs >= 1024 ? 1024 : (bs >= 256 ? 256 : 64);
     const int R = bs > T ? bs / T : 1;
     const int need = L * R;  // register slots per lane
+    // algorithmic bytes 12N + 4M per cloud, (M-1)*N pair evaluations of 8 flop
+    const double tot_n = A.stack ? (double)n_max : (double)nclouds * A.n_batch, tot_m = A.stack ? tot_n / 4 : (double)nclouds * A.m_batch;
+    KtScope kt(KT_FPS, st, 12.0 * tot_n + 4.0 * tot_m, A.stack ? 0.0 : 8.0 * nclouds * ((double)A.m_batch - 1) * A.n_batch);
     bool ok;
     if (T == 1024) ok = launch_fps_t<1024>(need, nclouds, A, st);
     else if (T == 256) ok = launch_fps_t<256>(need, nclouds, A, st);

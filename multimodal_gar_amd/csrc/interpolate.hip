@@ -395,6 +395,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_nn_batch(int b,
     if (b == 0 || n == 0) return MGAR_OK;
     MGAR_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn_batch: null pointer");
     dim3 grid(ceil_div(n, TN_THREADS), b);
+    KtScope kt(KT_THREE_NN, (hipStream_t)stream, (double)b * (12.0 * n + 12.0 * m + 24.0 * n));
     hipLaunchKernelGGL(three_nn_kernel<false>, grid, dim3(TN_THREADS), 0, (hipStream_t)stream, b, n, m, unknown,
                        (const int *)nullptr, known, (const int *)nullptr, dist2, idx);
     return check_launch("three_nn_batch: launch failed");
@@ -408,6 +409,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_nn_stack(int ba
     MGAR_REQUIRE(unknown && dist2 && idx && unknown_batch_cnt && known_batch_cnt && (known || M == 0),
                  "three_nn_stack: null pointer");
     dim3 grid(ceil_div(N, TN_THREADS) + batch_size);
+    KtScope kt(KT_THREE_NN, (hipStream_t)stream, 12.0 * N + 12.0 * M + 24.0 * N);
     hipLaunchKernelGGL(three_nn_kernel<true>, grid, dim3(TN_THREADS), 0, (hipStream_t)stream, batch_size, 0, 0, unknown,
                        unknown_batch_cnt, known, known_batch_cnt, dist2, idx);
     return check_launch("three_nn_stack: launch failed");
@@ -419,6 +421,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_bat
     MGAR_REQUIRE(b <= 65535, "three_interpolate_batch: b > 65535");
     if ((long long)b * c * n == 0) return MGAR_OK;
     MGAR_REQUIRE(points && idx && weight && out, "three_interpolate_batch: null pointer");
+    KtScope kt(KT_THREE_INTERP_FWD, (hipStream_t)stream, (double)b * (24.0 * n + 16.0 * c * n));
     if (m <= TI_LDS_MAX_FLOATS) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -521,6 +524,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
     ch = ch >= 8 ? 8 : (ch >= 4 ? 4 : (ch >= 2 ? 2 : 1));
     while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
     hipStream_t st = (hipStream_t)stream;
+    KtScope kt(KT_THREE_INTERP_BWD, st, (double)b * (24.0 * n + 16.0 * c * n));
     if (ch == 8) launch_bwd_sorted<8>(b, c, n, m, grad_out, list, grad_points, st);
     else if (ch == 4) launch_bwd_sorted<4>(b, c, n, m, grad_out, list, grad_points, st);
     else if (ch == 2) launch_bwd_sorted<2>(b, c, n, m, grad_out, list, grad_points, st);

@@ -109,6 +109,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd(co
     };
     Pool3dGeom g{T, H, W, (T + st - 1) / st, (H + sh - 1) / sh, (W + sw - 1) / sw, kt, kh, kw, st, sh, sw,
                  front(T, kt, st), front(H, kh, sh), front(W, kw, sw)};
+    KtScope ktimer(KT_MAXPOOL3D, (hipStream_t)stream, 4.0 * NC * ((double)T * H * W + (double)g.To * g.Ho * g.Wo));
     const bool vec1 = kw == 3 && sw == 1 && g.pw == 1, vec2 = kw == 3 && sw == 2 && g.pw == 0 && W % 2 == 0;
     if ((vec1 || vec2) && W % 4 == 0 && g.Wo % 4 == 0 && g.To <= 65535 && NC <= 65535 && (!vec2 || W >= 8)) {
         dim3 grid(ceil_div(g.Ho * (g.Wo / 4), 256), g.To, NC);

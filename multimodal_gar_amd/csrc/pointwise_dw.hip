@@ -234,12 +234,15 @@ extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_dw_act
     const DwAct act{in_mean, in_invstd, in_gamma, in_beta, in_relu};
     int ob, ib;
     dw_blocks(Cin, Cout, ob, ib);
+    {
+    KtScope kt(KT_POINTWISE_DW, st, 4.0 * (double)B * P * (Cin + Cout), 2.0 * (double)B * P * Cin * Cout);
     if (ob == 1 && ib == 1) launch_dw<1, 1>(x, dy, B, Cin, Cout, P, act, workspace, st);
     else if (ob == 1 && ib == 2) launch_dw<1, 2>(x, dy, B, Cin, Cout, P, act, workspace, st);
     else if (ob == 1 && ib == 4) launch_dw<1, 4>(x, dy, B, Cin, Cout, P, act, workspace, st);
     else if (ob == 2 && ib == 1) launch_dw<2, 1>(x, dy, B, Cin, Cout, P, act, workspace, st);
     else if (ob == 2 && ib == 2) launch_dw<2, 2>(x, dy, B, Cin, Cout, P, act, workspace, st);
     else launch_dw<2, 4>(x, dy, B, Cin, Cout, P, act, workspace, st);
+    }
     const int gx = dw_grid_x(B, Cin, Cout, P, ob, ib), n_out = Cout * Cin;
     hipLaunchKernelGGL(pointwise_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(256), 0, st, workspace, gx, n_out, dw);
     return check_launch("pointwise_conv_dw: launch failed");

@@ -181,6 +181,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_fwd(co
     }
     PfArgs a{x, w, in_mean, in_invstd, in_gamma, in_beta, y, B, Cin, Cout, P, w_row_stride, w_col_stride, in_relu};
     hipStream_t st = (hipStream_t)stream;
+    KtScope kt(KT_POINTWISE_FWD, st, 4.0 * (double)B * P * (Cin + Cout), 2.0 * (double)B * P * Cin * Cout);
     if (Cout <= 32) launch_pf<1>(a, st);
     else launch_pf<2>(a, st);
     return check_launch("pointwise_conv_fwd: launch failed");

@@ -232,6 +232,7 @@ static int qg_batch_fwd(int b, int c, int n, int npoints, int nsample, const flo
     MGAR_REQUIRE(xyz && new_xyz && idx && (features || c == 0) && (y_out || c == 0) && (rel_out || y_out),
                  "query_group (batch) fwd: null pointer");
     dim3 grid(ceil_div((long long)npoints * nsample, 256), 1 + ceil_div(c, QG_CCHUNK), b);
+    KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)b * npoints * nsample * (4.0 + 8.0 * (c + 3)));
     hipLaunchKernelGGL(qg_batch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, nsample, xyz, new_xyz,
                        features, wx, idx, rel_out, rel_bstride, y_out, y_bstride);
     return check_launch(what);
@@ -244,6 +245,7 @@ static int qg_batch_bwd(int b, int c, int n, int npoints, int nsample, const flo
     const int cols = npoints * nsample;
     if ((long long)b * c * cols == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_y && idx && grad_features, "query_group (batch) bwd: null pointer");
+    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)b * cols * (4.0 + 8.0 * c));
     if (n <= QG_LDS_MAX_FLOATS) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -297,6 +299,7 @@ static int qg_stack_fwd(int B, int M, int C, int nsample, const float *xyz, cons
     if (B == 0 || total == 0) return MGAR_OK;
     MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && (features || C == 0) && (y_out || C == 0) &&
                      (rel_out || y_out), "query_group (stack) fwd: null pointer");
+    KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)total * (4.0 + 8.0 * (C + 3)));
     hipLaunchKernelGGL(qg_stack_fwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
                        xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, ld, wx, idx, rel_out, y_out);
     return check_launch(what);
@@ -308,6 +311,7 @@ static int qg_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, c
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0 || C == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_y && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group (stack) bwd: null pointer");
+    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)total * (4.0 + 8.0 * C));
     hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
                        grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features, ld);
     return check_launch(what);

@@ -137,9 +137,12 @@ extern "C" __attribute__((visibility("default"))) int mgar_rowmajor_dw(const flo
         return MGAR_EUNSUPPORTED;
     }
 #define RD_CASE(O, I) if (ob == O && ib == I) launch_rd<O, I>(a, lda, f, ldf, N, Co, Ci, workspace, st);
+    {
+    KtScope kt(KT_ROWMAJOR_DW, st, 4.0 * (double)N * (Co + Ci), 2.0 * (double)N * Co * Ci);
     RD_CASE(1, 1) RD_CASE(1, 2) RD_CASE(1, 3) RD_CASE(1, 4)
     RD_CASE(2, 1) RD_CASE(2, 2) RD_CASE(2, 3) RD_CASE(2, 4)
     RD_CASE(3, 1) RD_CASE(3, 2) RD_CASE(3, 3) RD_CASE(3, 4)
+    }
 #undef RD_CASE
     const int np = rd_workgroups(N) * 4, n_out = Co * Ci;
     hipLaunchKernelGGL(rowmajor_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(256), 0, st, workspace, np, n_out, dw);

@@ -375,3 +375,22 @@ def test_conv1x1_uses_dw_kernel_and_matches_torch_conv():
     yr = ref(xd)
     yr.backward(g.double().cpu())
     close(y, yr); close(x.grad, xd.grad); close(conv.weight.grad, ref.weight.grad, rtol=5e-5)
+
+
+def test_kernel_timers_bracket_launches():
+    """mgar_ktimer_*: HIP events around instrumented launches + the launch's algorithmic bytes."""
+    from multimodal_gar_amd import _lib as L, bn_ops
+    bn = torch.nn.BatchNorm1d(8).cuda().train()
+    x = torch.randn(4, 8, 4096, device="cuda")
+    L.kernel_timers(enable=True); L.kernel_timers()
+    try:
+        for _ in range(3):
+            bn_ops.bn_act(x, bn, True)
+        torch.cuda.synchronize()
+    finally:
+        L.kernel_timers(enable=False)
+    t = L.kernel_timers()
+    assert t["bn_partial_kernel"][1] == 3 and t["bn_apply_kernel"][1] == 3
+    assert t["bn_partial_kernel"][2] == 3 * 4 * x.numel() and t["bn_apply_kernel"][2] == 3 * 8 * x.numel()
+    assert 0 < t["bn_partial_kernel"][0] < 50 and 0 < t["bn_apply_kernel"][0] < 50
+    assert L.kernel_timers() == {}            # reset by the read above; nothing recorded while disabled
