@@ -226,7 +226,9 @@ int mgar_rowmajor_dw(const float *a, int lda, const float *f, int ldf, long long
  *                 non-NULL they receive the usual momentum update (unbiased variance) and the int64
  *                 counter num_batches_tracked (may be NULL) is incremented.
  *   act_fwd     : y = [relu](x * gamma*invstd + beta - mean*gamma*invstd)   (gamma/beta may be NULL)
- *   act_maxpool_fwd : out (B,C,M) = max_s [relu](bn(x[b,c,m,s])), arg (B,C,M) uint8 = first arg-max
+ *   act_maxpool_fwd : out (B,C,M) = max_s [relu](bn(x[b,c,m,s])), arg (B,C,M) uint8 = first arg-max,
+ *                 xarg (B,C,M, may be NULL) = x at the arg-max (lets the backward reduction read
+ *                 coalesced arrays; act_maxpool_bwd gathers from x when it is NULL)
  *   act_bwd     : dx, dgamma, dbeta of y = [relu](bn_train(x)) given dy (all fully written)
  *   act_maxpool_bwd : the same when y was reduced by act_maxpool_fwd (dpool, pooled, arg) */
 int mgar_bn_workspace_floats(int B, int C, int P);
@@ -237,12 +239,12 @@ int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, cons
                     const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean,
                             const float *invstd, const float *gamma, const float *beta, int relu, float *out,
-                            unsigned char *arg, void *stream);
+                            unsigned char *arg, float *xarg, void *stream);
 int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
                     float *dbeta, float *dx, void *stream);
 int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x,
-                            int B, int C, int M, int nsample, const float *mean, const float *invstd,
+                            const float *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd,
                             const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta,
                             float *dx, void *stream);
 

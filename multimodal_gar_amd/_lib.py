@@ -57,9 +57,9 @@ _PROTOS = {
     "mgar_bn_workspace_floats": [_I, _I, _I],
     "mgar_bn_train_stats": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
-    "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
-    "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_pointwise_conv_dw": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "mgar_pointwise_dw_workspace_floats": [_I, _I, _I, _I],
     "mgar_pointwise_conv_dw_act": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],

@@ -68,9 +68,10 @@ class _BnActMaxPool(Function):
         b, c, m, ns = x4.shape
         out = torch.empty((b, c, m), dtype=torch.float32, device=x4.device)
         arg = torch.empty((b, c, m), dtype=torch.uint8, device=x4.device)
+        xarg = torch.empty((b, c, m), dtype=torch.float32, device=x4.device) if x4.requires_grad or gamma.requires_grad else None
         L.call("mgar_bn_act_maxpool_fwd", L.fptr(x4), b, c, m, ns, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
-               int(relu), L.fptr(out), _u8ptr(arg), L.stream_of(x4))
-        ctx.save_for_backward(x4, gamma, mean, invstd, out, arg)
+               int(relu), L.fptr(out), _u8ptr(arg), L.fptr(xarg), L.stream_of(x4))
+        ctx.save_for_backward(x4, gamma, mean, invstd, out, arg, xarg)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(arg)
         return out, arg
@@ -78,12 +79,12 @@ class _BnActMaxPool(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dpool, darg=None):
-        x4, gamma, mean, invstd, out, arg = ctx.saved_tensors
+        x4, gamma, mean, invstd, out, arg, xarg = ctx.saved_tensors
         b, c, m, ns = x4.shape
         dx = torch.empty_like(x4)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dpool_c, ws = dpool.contiguous(), _workspace(x4, b, c, m * ns)
-        L.call("mgar_bn_act_maxpool_bwd", L.fptr(dpool_c), L.fptr(out), _u8ptr(arg), L.fptr(x4), b, c, m, ns,
+        L.call("mgar_bn_act_maxpool_bwd", L.fptr(dpool_c), L.fptr(out), _u8ptr(arg), L.fptr(x4), L.fptr(xarg), b, c, m, ns,
                L.fptr(mean), L.fptr(invstd), L.fptr(gamma), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta),
                L.fptr(dx), L.stream_of(x4))
         return dx, dgamma, dbeta, None, None, None

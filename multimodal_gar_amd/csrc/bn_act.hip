@@ -160,7 +160,8 @@ template <bool RELU, int G>   // G = NS / 4 lanes per group: 1, 2, 4, 8 or 16
 __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__restrict__ x, int C, int M, int NS,
                                                                 const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                float *__restrict__ out, unsigned char *__restrict__ arg) {
+                                                                float *__restrict__ out, unsigned char *__restrict__ arg,
+                                                                float *__restrict__ xarg) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
@@ -186,6 +187,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__r
         const long long m = q / G;
         out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
         arg[(size_t)row * M + m] = (unsigned char)bi;
+        // the pre-BN value at the arg-max (the line was just read: an L1/L2 hit), so that the backward
+        // reduction reads three coalesced (B,C,M) arrays instead of gathering one element per group
+        if (xarg) xarg[(size_t)row * M + m] = x[(size_t)row * M * NS + m * NS + bi];
     }
 }
 
@@ -194,7 +198,8 @@ template <bool RELU>
 __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restrict__ x, int C, int M, int NS,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            float *__restrict__ out, unsigned char *__restrict__ arg) {
+                                                            float *__restrict__ out, unsigned char *__restrict__ arg,
+                                                            float *__restrict__ xarg) {
     const int row = blockIdx.x;
     const int m = blockIdx.y * BN_THREADS + threadIdx.x;
     if (m >= M) return;
@@ -210,6 +215,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restr
     }
     out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
     arg[(size_t)row * M + m] = (unsigned char)bi;
+    if (xarg) xarg[(size_t)row * M + m] = xr[bi];
 }
 
 // ---- backward reduction: 8 B read per element ---------------------------------------------------
@@ -261,7 +267,8 @@ template <bool RELU>
 __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const float *__restrict__ dpool,
                                                                         const float *__restrict__ pooled,
                                                                         const unsigned char *__restrict__ arg,
-                                                                        const float *__restrict__ x, int B, int C, int M, int NS,
+                                                                        const float *__restrict__ x,
+                                                                        const float *__restrict__ xarg, int B, int C, int M, int NS,
                                                                         const float *__restrict__ mean,
                                                                         const float *__restrict__ invstd,
                                                                         float *__restrict__ partial) {
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const fl
         const size_t o = chan_off(e, c, C, M);
         float d = dpool[o];
         if (RELU && !(pooled[o] > 0.f)) d = 0.f;
-        const float xh = (x[o * NS + arg[o]] - mu) * is;
+        const float xh = ((xarg ? xarg[o] : x[o * NS + arg[o]]) - mu) * is;
         s += d;
         q += d * xh;
     }
@@ -442,7 +449,7 @@ BN_API int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mea
 
 BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean, const float *invstd,
                                    const float *gamma, const float *beta, int relu, float *out, unsigned char *arg,
-                                   void *stream) {
+                                   float *xarg, void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_fwd: bad sizes");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(x && out && arg && mean && invstd, "bn_act_maxpool_fwd: null pointer");
@@ -452,8 +459,8 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
 #define BN_MAX_VEC(G)                                                                                                  \
     {                                                                                                                  \
         dim3 gv(B * C, ceil_div((long long)M * (G), BN_THREADS));                                                      \
-        if (relu) hipLaunchKernelGGL((bn_max_vec_kernel<true, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg); \
-        else hipLaunchKernelGGL((bn_max_vec_kernel<false, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);     \
+        if (relu) hipLaunchKernelGGL((bn_max_vec_kernel<true, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg); \
+        else hipLaunchKernelGGL((bn_max_vec_kernel<false, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);     \
     }
     if (nsample == 4) BN_MAX_VEC(1)
     else if (nsample == 8) BN_MAX_VEC(2)
@@ -462,8 +469,8 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
     else if (nsample == 64) BN_MAX_VEC(16)
     else {
         dim3 grid(B * C, ceil_div(M, BN_THREADS));
-        if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
-        else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg);
+        if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);
+        else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);
     }
 #undef BN_MAX_VEC
     return check_launch("bn_act_maxpool_fwd: launch failed");
@@ -492,8 +499,8 @@ BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P,
     return check_launch("bn_act_bwd: launch failed");
 }
 
-BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x, int B, int C,
-                                   int M, int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
+BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x,
+                                   const float *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
                                    float *workspace, float *dgamma, float *dbeta, float *dx, void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_bwd: bad sizes");
     if ((long long)B * C * M == 0) return MGAR_OK;
@@ -503,8 +510,8 @@ BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, cons
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_MAX_BWD_REDUCE, st, 13.0 * (double)B * C * M);
-    if (relu) hipLaunchKernelGGL(bn_max_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
-    else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, B, C, M, nsample, mean, invstd, workspace);
+    if (relu) hipLaunchKernelGGL(bn_max_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
+    else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
     }
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);

@@ -71,24 +71,43 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
+    // register prefetch (vector path): the global loads of tile t+1 are in flight while the MFMAs of
+    // tile t run; the LDS tile is single-buffered
+    constexpr int NV = (OB + IB) * 32 * (DW_TP / 4) / 256;   // float4 per thread and tile
+    float4 pre[NV];
+    auto fetch = [&](long long tile) {
+        const int b = (int)(tile / tiles_per_b);
+        const int p0 = (int)(tile - (long long)b * tiles_per_b) * DW_TP;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int row = e / (DW_TP / 4), c4 = (e - row * (DW_TP / 4)) * 4;
+            const bool is_y = row < OB * 32;
+            const int ch = is_y ? o_base + row : i_base + row - OB * 32;
+            const int cmax = is_y ? Cout : Cin;
+            pre[u] = (ch < cmax && p0 + c4 < P)
+                         ? *reinterpret_cast<const float4 *>((is_y ? dy : x) + ((size_t)b * cmax + ch) * P + p0 + c4)
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (vec && (long long)blockIdx.x < total_tiles) fetch(blockIdx.x);
+
     for (long long tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
         const int b = (int)(tile / tiles_per_b);
         const int p0 = (int)(tile - (long long)b * tiles_per_b) * DW_TP;
         // ---- stage (OB + IB) * 32 rows x 128 columns, zero-padded ----
         if (vec) {
-            for (int e = threadIdx.x; e < (OB + IB) * 32 * (DW_TP / 4); e += 256) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) {
+                const int e = threadIdx.x + u * 256;
                 const int row = e / (DW_TP / 4), c4 = (e - row * (DW_TP / 4)) * 4;
                 const bool is_y = row < OB * 32;
                 const int ch = is_y ? o_base + row : i_base + row - OB * 32;
-                const int cmax = is_y ? Cout : Cin;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ch < cmax && p0 + c4 < P) {
-                    v = *reinterpret_cast<const float4 *>((is_y ? dy : x) + ((size_t)b * cmax + ch) * P + p0 + c4);
-                    if (has_act && !is_y) {
-                        const float sc = act_sc[row - OB * 32], sh = act_sh[row - OB * 32];
-                        v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
-                        if (act.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    }
+                float4 v = pre[u];
+                if (has_act && !is_y && ch < Cin && p0 + c4 < P) {   // padding stays zero
+                    const float sc = act_sc[row - OB * 32], sh = act_sh[row - OB * 32];
+                    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                    if (act.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 }
                 float *d = lds + row * DW_LD + c4;
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
@@ -111,6 +130,7 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
             }
         }
         __syncthreads();
+        if (vec && tile + gridDim.x < total_tiles) fetch(tile + gridDim.x);
         // ---- this wave's 32 columns: 16 k-steps of 2 columns ----
         const int colw = wave * 32 + (lane >> 5);
 #pragma unroll 4
