@@ -102,6 +102,11 @@ def main():
         x = torch.randn(f, 32, m * 32, device="cuda"); dy = torch.randn(f, 64, m * 32, device="cuda")
         rec("pointwise_dw Cin=32 Cout=64 P=%d" % (m * 32), timeit(lambda: nn_utils.pointwise_dw(x, dy), a.iters), x.numel() * 4 + dy.numel() * 4)
         del x, dy
+        for cin, cout, cols in ((64, 128, 1024 * 32), (96, 128, 1024 * 32), (128, 196, 256 * 32), (196, 256, 256 * 32), (64, 64, 1024 * 16)):
+            x = torch.randn(f, cin, cols, device="cuda"); dy = torch.randn(f, cout, cols, device="cuda")
+            rec("pointwise_dw Cin=%d Cout=%d P=%d" % (cin, cout, cols), timeit(lambda: nn_utils.pointwise_dw(x, dy), a.iters), x.numel() * 4 + dy.numel() * 4)
+            rec("   library  sum_b dy[b] x[b]^T", timeit(lambda: torch.einsum("bop,bip->oi", dy, x), a.iters), x.numel() * 4 + dy.numel() * 4)
+            del x, dy
     if "pw" in only:
         from multimodal_gar_amd import _lib as L
         for cin, cout, ns in ((16, 16, 16), (16, 32, 16), (32, 32, 32), (32, 64, 32), (64, 64, 16)):
