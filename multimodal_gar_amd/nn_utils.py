@@ -34,7 +34,6 @@ class _PointwiseConv(torch.autograd.Function):
 
 
 _DW_MIN_COLUMNS = 1 << 16   # below this the library GEMM is fine
-_DW_MAX_CHANNELS = 512      # tools/microbench.py --only dw: 2-6x faster than the library's batched dW up to 196 x 256
 
 
 def pointwise_dw(x3, dy):
@@ -57,7 +56,7 @@ def conv1x1(conv, x):
     # the batch into the GEMM's rows and hand back a TRANSPOSED view, which the next op then
     # materialises with a slow strided copy of the whole activation.)
     if (x3.is_cuda and x3.dtype == torch.float32 and x3.shape[0] * x3.shape[2] >= _DW_MIN_COLUMNS
-            and conv.out_channels <= _DW_MAX_CHANNELS and conv.in_channels <= _DW_MAX_CHANNELS
+            and conv.out_channels <= 64 and conv.in_channels <= 128   # one pass over both operands (OB <= 2, IB <= 4)
             and torch.is_grad_enabled() and conv.weight.requires_grad):
         y = _PointwiseConv.apply(x3, w[0].contiguous())
     else:
