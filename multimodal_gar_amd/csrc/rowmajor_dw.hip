@@ -19,13 +19,16 @@ namespace mgar {
 
 typedef float __attribute__((ext_vector_type(16))) f32x16;
 
-constexpr int RD_ROWS = 16;  // rows per slab = 8 MFMA k-steps
+// rows per slab = 2 * KS (KS MFMA k-steps): 16, or 8 where the Co x Ci accumulator leaves fewer registers for
+// the two prefetch buffers (a <3,4> instance with 16-row slabs spilled 81 VGPRs to scratch)
+template <int OB, int IB> struct RdSlab { static constexpr int KS = OB * IB > 6 ? 4 : 8; };
 
 template <int OB, int IB>
 __global__ __launch_bounds__(256) void rowmajor_dw_kernel(const float *__restrict__ A, int lda, const float *__restrict__ F, int ldf,
                                                           long long N, int Co, int Ci, float *__restrict__ partial) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = lane & 31, h = lane >> 5;
+    constexpr int KS = RdSlab<OB, IB>::KS, RD_ROWS = 2 * KS;
     const long long nslab = (N + RD_ROWS - 1) / RD_ROWS;
     const long long wave_id = (long long)blockIdx.x * 4 + wave, nwaves = (long long)gridDim.x * 4;
 
@@ -37,10 +40,10 @@ __global__ __launch_bounds__(256) void rowmajor_dw_kernel(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    auto issue = [&](long long slab, float (&av)[8][OB], float (&fv)[8][IB]) {
+    auto issue = [&](long long slab, float (&av)[KS][OB], float (&fv)[KS][IB]) {
         const long long n0 = slab * RD_ROWS + h;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const long long n = n0 + 2 * ks;
             const bool ok = n < N;
 #pragma unroll
@@ -49,16 +52,16 @@ __global__ __launch_bounds__(256) void rowmajor_dw_kernel(const float *__restric
             for (int c = 0; c < IB; ++c) fv[ks][c] = (ok && c * 32 + l < Ci) ? F[(size_t)n * ldf + c * 32 + l] : 0.f;
         }
     };
-    auto compute = [&](float (&av)[8][OB], float (&fv)[8][IB]) {
+    auto compute = [&](float (&av)[KS][OB], float (&fv)[KS][IB]) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int a = 0; a < OB; ++a)
 #pragma unroll
                 for (int c = 0; c < IB; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks][a], fv[ks][c], acc[a][c], 0, 0, 0);
     };
 
-    float a0[8][OB], f0[8][IB], a1[8][OB], f1[8][IB];
+    float a0[KS][OB], f0[KS][IB], a1[KS][OB], f1[KS][IB];
     long long slab = wave_id;
     if (slab < nslab) issue(slab, a0, f0);
     while (slab < nslab) {
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256) void rowmajor_dw_reduce_kernel(const float *__
 }
 
 static int rd_workgroups(long long N) {
-    const long long nslab = (N + RD_ROWS - 1) / RD_ROWS;
+    const long long nslab = (N + 15) / 16;
     long long wgs = (nslab + 4 * 8 - 1) / (4 * 8);  // at least 8 slabs per wave
     if (wgs > 256) wgs = 256;                        // one workgroup per CU: the accumulator fills the register file
     if (wgs < 1) wgs = 1;

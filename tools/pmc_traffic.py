@@ -1,0 +1,69 @@
+"""HBM traffic per launch of the hand-written kernels from two rocprofv3 PMC passes of bench.py.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out_fetch -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out_write -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing
+    python tools/pmc_traffic.py out_fetch/p_counter_collection.csv out_write/p_counter_collection.csv > profiles/pmc_hbm_traffic.json
+
+Counters are in KiB (/opt/skills/guides/cdna_hip_programming.md: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024) and are
+collected in SEPARATE passes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2).  gfx950 correction
+(MI355X_MICROARCH.md, section HBM): FETCH_SIZE reports exactly half of the bytes of a wide (16 B / lane)
+coalesced streaming read, so the read side of the kernels listed in WIDE_READERS -- whose global reads
+are all float4 -- is doubled; WRITE_SIZE is exact for 16-byte stores and float atomics.  Kernels that
+read through 4-byte gathers are reported uncorrected and flagged "uncalibrated".  Both steps of the run
+(warm-up + timed) execute the same launches, so the average is over all launches of a kernel."""
+import collections
+import csv
+import json
+import sys
+
+# ktimer name (csrc/errors.hip) -> substring of the kernel symbol
+KERNELS = {
+    "bn_partial_kernel": "mgar::bn_partial_kernel", "bn_apply_kernel": "mgar::bn_apply_kernel", "bn_max_vec_kernel": "mgar::bn_max_vec_kernel",
+    "bn_bwd_partial_kernel": "mgar::bn_bwd_partial_kernel", "bn_bwd_apply_kernel": "mgar::bn_bwd_apply_kernel",
+    "bn_max_bwd_partial_kernel": "mgar::bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel": "mgar::bn_max_bwd_apply_kernel",
+    "pointwise_fwd_kernel": "mgar::pointwise_fwd_kernel", "pointwise_dw_kernel": "mgar::pointwise_dw_kernel<",
+    "rowmajor_dw_kernel": "mgar::rowmajor_dw_kernel", "maxpool3d_same_kernel": "mgar::maxpool3d_same",
+    "fps_kernel": "mgar::fps_kernel", "ball_query_kernel": "mgar::ball_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
+    "three_interp_fwd": "mgar::three_interp_batch_fwd", "three_interp_bwd": "mgar::three_interp_batch_bwd",
+    "query_group_fwd": "_fwd_kernel(int, int, int, int, float const*", "query_group_bwd": "mgar::qg_",
+}
+WIDE_READERS = {"bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel",
+                "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel", "pointwise_dw_kernel", "maxpool3d_same_kernel"}
+
+
+def per_kernel(path, counter):
+    tot = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        n = r["Kernel_Name"]
+        for key, sub in KERNELS.items():
+            if sub in n and not (key == "query_group_bwd" and "bwd" not in n) and not (key == "query_group_fwd" and "qg_" not in n):
+                t = tot[key]
+                t[0] += float(r["Counter_Value"]) * 1024.0
+                t[1] += 1
+                break
+    return tot
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"unit": "bytes per launch (HBM-side, FETCH_SIZE [x2 for float4 streaming readers] + WRITE_SIZE, KiB * 1024)",
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 at config c3",
+           "per_launch_bytes": {}, "detail": {}}
+    for k in KERNELS:
+        if k not in fetch or k not in write:
+            continue
+        f = fetch[k][0] / fetch[k][1]
+        w = write[k][0] / write[k][1]
+        wide = k in WIDE_READERS
+        total = (2.0 * f if wide else f) + w
+        out["per_launch_bytes"][k] = round(total)
+        out["detail"][k] = {"launches": fetch[k][1], "fetch_size_bytes_raw": round(f), "write_size_bytes": round(w),
+                            "read_correction": "x2 (16 B/lane streaming reads)" if wide else "none (uncalibrated: 4-byte gathers / scalar streams)"}
+    json.dump(out, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
