@@ -194,10 +194,7 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find   # MIOpen find mode for the I3D convolutions
     log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
     step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp)
-    # two-stream issue of the RGB / LiDAR branches only without DDP: the reducer synchronises a gradient bucket
-    # with the stream of the hook that completes it, so gradients born on two streams could race (and at c3 both
-    # branches fill the chip anyway: the overlap only hides launch gaps)
-    step.module.overlap_branches = not args.no_overlap and not ddp
+    step.module.overlap_branches = not args.no_overlap   # frozen I3D on a side stream (no autograd there: DDP-safe)
     batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
 
     def barrier():

@@ -45,8 +45,11 @@ class PointNet2MSG(nn.Module):
         if features is not None:
             features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
         l_xyz, l_features = [xyz], [features]
-        for sa in self.SA_modules:
-            li_xyz, li_features = sa(l_xyz[-1], l_features[-1])
+        # optional: centres picked ahead of time by the caller (same FPS, issued earlier so that it overlaps other
+        # work -- one workgroup per cloud leaves most of the chip idle); SA modules take new_xyz as in the reference
+        pre = batch_dict.get('sa_new_xyz') or []
+        for k, sa in enumerate(self.SA_modules):
+            li_xyz, li_features = sa(l_xyz[-1], l_features[-1], new_xyz=pre[k] if k < len(pre) else None)
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):

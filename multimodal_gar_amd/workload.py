@@ -122,25 +122,48 @@ class ClipModel(nn.Module):
         self._side_stream = None
 
     # ---- RGB: one I3D pass per clip (batch 1, like the reference) ---------------------------------
-    def rgb_tokens(self, images, bboxes):
+    def rgb_crops(self, images, bboxes):
+        """Frozen part of the RGB branch (I3D_FREEZE): I3D + RoIAlign per clip, no autograd graph."""
+        rb = self.net.RGB_backbone
+        crops = []
+        with torch.no_grad():
+            for b in range(images.shape[0]):
+                clip = images[b:b + 1]
+                _B, _T, _C, _H, _W = clip.shape
+                clip = clip.view(_B, _C, _T, _H, _W)             # the reference's view (gat_model.py:1836)
+                crops.append(rb.crop_features(clip, [bboxes[b]]))  # (A+1, 832, 5, 5)
+        return crops
+
+    def rgb_tokens_from_crops(self, crops):
+        """Trainable tail: non-local block, pooling, embedding, optional GAT -> (B, A, 512)."""
         from .model.gat_model import fully_connected_edges
         rb = self.net.RGB_backbone
         a = self.n_actors
         toks = []
-        for b in range(images.shape[0]):
-            clip = images[b:b + 1]
-            _B, _T, _C, _H, _W = clip.shape
-            clip = clip.view(_B, _C, _T, _H, _W)                 # the reference's view (gat_model.py:1836)
-            with torch.no_grad():                                # I3D is frozen (I3D_FREEZE)
-                crops = rb.crop_features(clip, [bboxes[b]])      # (A+1, 832, 5, 5)
-            tok = rb.embed(crops[:a])                            # (A, 512)
+        for c in crops:
+            tok = rb.embed(c[:a])                                # (A, 512)
             if rb.cfg.GAT_module:
                 tok = rb.GAT_module(tok, fully_connected_edges([a], tok.device))
             toks.append(tok)
-        return torch.stack(toks)                                 # (B, A, 512)
+        return torch.stack(toks)
+
+    def rgb_tokens(self, images, bboxes):
+        return self.rgb_tokens_from_crops(self.rgb_crops(images, bboxes))
 
     # ---- LiDAR: all frames of all clips in one batch ------------------------------------------------
-    def lidar_tokens(self, points, bboxes3d):
+    def first_level_centres(self, points):
+        """Level-1 farthest point sampling of the PointNet++ trunk, callable ahead of the trunk: FPS runs one
+        workgroup per cloud for ~7 ms (6-47 % of the CUs), so it is issued first and overlaps the I3D work."""
+        if self.route != "pointnet2":
+            return None
+        from .pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pb
+        sa0 = self.net.LiDAR_backbone.model.backbone_3d.SA_modules[0]
+        with torch.no_grad():
+            xyz = points[..., :3].contiguous()
+            picked = pb.farthest_point_sample(xyz, sa0.npoint)
+            return pb.gather_operation(xyz.transpose(1, 2).contiguous(), picked).transpose(1, 2).contiguous()
+
+    def lidar_tokens(self, points, bboxes3d, new_xyz1=None):
         f, p, _ = points.shape
         a = self.n_actors
         lb = self.net.LiDAR_backbone
@@ -149,6 +172,8 @@ class ClipModel(nn.Module):
             data = {"batch_size": f, "points": torch.cat([bidx, points], -1).view(f * p, 5),
                     "gt_boxes": bboxes3d[:, :a, :].contiguous(),
                     "point_batch_cnt": torch.full((f,), p, dtype=torch.int32, device=points.device)}
+            if new_xyz1 is not None:
+                data["sa_new_xyz"] = [new_xyz1]
         else:
             data = voxelize_batch(points, self.dataset)
             data["gt_boxes"] = bboxes3d[:, :a, :].contiguous()
@@ -158,18 +183,23 @@ class ClipModel(nn.Module):
     def forward(self, batch):
         b, t, a = batch["n_clips"], batch["n_frames"], self.n_actors
         if batch["images"].is_cuda and self.overlap_branches:
-            # The RGB branch (I3D convolutions: MFMA-heavy) and the LiDAR branch (HBM-bound kernels)
-            # are independent until the fusion model: run the RGB branch on a side HIP stream so the
-            # two overlap on the chip.  Autograd replays each op's backward on its forward stream.
+            # The frozen I3D pass (MFMA-heavy convolutions, no autograd graph) runs on a side HIP stream next to the
+            # LiDAR branch on the main stream.  Issue order: level-1 FPS first (a single launch that leaves most of
+            # the chip idle), then the I3D launches, then the rest of the LiDAR branch.  Nothing that autograd will
+            # replay lives on the side stream, so gradient hooks (DDP) only ever see the main stream.
             main = torch.cuda.current_stream()
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream()
-            self._side_stream.wait_stream(main)
+            inputs_ready = main.record_event()
+            new_xyz1 = self.first_level_centres(batch["points"])
+            self._side_stream.wait_event(inputs_ready)
             with torch.cuda.stream(self._side_stream):
-                rgb = self.rgb_tokens(batch["images"], batch["bboxes"])             # (B, A, 512)
-            lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])           # (B*T, A, 512)
+                crops = self.rgb_crops(batch["images"], batch["bboxes"])
+            lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], new_xyz1)   # (B*T, A, 512)
             main.wait_stream(self._side_stream)
-            rgb.record_stream(main)
+            for c in crops:
+                c.record_stream(main)
+            rgb = self.rgb_tokens_from_crops(crops)                                   # (B, A, 512)
         else:
             rgb = self.rgb_tokens(batch["images"], batch["bboxes"])
             lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])
