@@ -81,6 +81,16 @@ int mgar_gather_points_grad_batch(int b, int c, int n, int npoints,
  * strided scan + shared-memory tree would (FPS tie rule). */
 int mgar_fps_batch(int b, int n, int m, const float *points, float *temp, int *idx, void *stream);
 
+/* The same sampling with spatial pruning (same indices, bit for bit): `perm` (b,n) lists every cloud's
+ * point indices in a spatially coherent order -- any permutation is correct, a Morton order is fast:
+ * the 64*ceil(n/1024) points of a wave then form a compact cluster and the wave skips the distance
+ * update of a round whenever the new sample is farther from its bounding box than its current
+ * maximum distance.  mgar_morton_codes writes 30-bit Morton codes (b,n) for the caller to sort.
+ * Needs 1024 <= n <= 16384 (MGAR_EUNSUPPORTED otherwise: use mgar_fps_batch). */
+int mgar_morton_codes(int b, int n, const float *points, int *codes, void *stream);
+int mgar_fps_batch_perm(int b, int n, int m, const float *points, float *temp, const int *perm, int *idx,
+                        void *stream);
+
 /* three_nn_wrapper   pointnet2_api.cpp:21;  kernel interpolate_gpu.cu:16-59
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3). */
 int mgar_three_nn_batch(int b, int n, int m, const float *unknown, const float *known,

@@ -29,6 +29,8 @@ _PROTOS = {
     "mgar_gather_points_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_gather_points_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_fps_batch": [_I, _I, _I, _P, _P, _P, _P],
+    "mgar_morton_codes": [_I, _I, _P, _P, _P],
+    "mgar_fps_batch_perm": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],

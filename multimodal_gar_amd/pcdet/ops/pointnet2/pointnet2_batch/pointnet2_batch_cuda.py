@@ -44,6 +44,17 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     return 1
 
 
+def farthest_point_sampling_pruned_wrapper(b, n, m, points, temp, idx):
+    """Same result as farthest_point_sampling_wrapper; points are visited in Morton order so that whole waves can
+    skip the distance update of a round (csrc/fps.hip, fps_pruned_kernel).  1024 <= n <= 16384."""
+    import torch
+    codes = torch.empty((b, n), dtype=torch.int32, device=points.device)
+    L.call("mgar_morton_codes", b, n, L.fptr(points), L.iptr(codes), L.stream_of(points))
+    perm = torch.sort(codes, dim=1).indices.int()
+    L.call("mgar_fps_batch_perm", b, n, m, L.fptr(points), L.fptr(temp), L.iptr(perm), L.iptr(idx), L.stream_of(points))
+    return 1
+
+
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     L.call("mgar_three_nn_batch", b, n, m, L.fptr(unknown), L.fptr(known), L.fptr(dist2), L.iptr(idx),
            L.stream_of(unknown))

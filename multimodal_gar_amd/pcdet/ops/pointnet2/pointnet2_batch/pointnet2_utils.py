@@ -25,6 +25,9 @@ def _new(like: torch.Tensor, shape, dtype, fill=None) -> torch.Tensor:
     return torch.full(shape, fill, dtype=dtype, device=like.device)
 
 
+PRUNED_FPS_MIN_POINTS = 2048   # below this the plain kernel is already short (csrc/fps.hip)
+
+
 class FarthestPointSampling(Function):
     """idx (B, npoint) int32 of an iterative farthest-point subset; first index is 0.
     Reference: pointnet2_utils.py:10-33 -> sampling_gpu.cu:101-216."""
@@ -35,7 +38,10 @@ class FarthestPointSampling(Function):
         batch, n_pts, _ = xyz.size()
         idx = _new(xyz, (batch, npoint), torch.int32)
         running_min = _new(xyz, (batch, n_pts), torch.float32, 1e10)
-        pointnet2.farthest_point_sampling_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
+        if xyz.is_cuda and PRUNED_FPS_MIN_POINTS <= n_pts <= 16384 and hasattr(pointnet2, "farthest_point_sampling_pruned_wrapper"):
+            pointnet2.farthest_point_sampling_pruned_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
+        else:
+            pointnet2.farthest_point_sampling_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
         ctx.mark_non_differentiable(idx)
         return idx
 

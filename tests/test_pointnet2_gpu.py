@@ -104,6 +104,37 @@ def test_fps_temp_inout(oracle):
     np.testing.assert_array_equal(t.cpu().numpy(), want_temp)
 
 
+@pytest.mark.parametrize("n,m,kind", [(1024, 200, "scene"), (2500, 600, "scene"), (4096, 1024, "lattice"), (16384, 4096, "scene"),
+                                      (9000, 9000, "lattice")])
+def test_fps_pruned_equals_plain_kernel(n, m, kind):
+    """mgar_fps_batch_perm (Morton order + per-wave skipping) must give the plain kernel's indices AND running
+    minima bit for bit -- with the Morton permutation, with a random one, and with a caller-provided temp."""
+    from multimodal_gar_amd import _lib as L
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as C
+    rng = np.random.default_rng(n + m)
+    xyz = scene_xyz(n + 1, 3, n) if kind == "scene" else lattice(rng, (3, n, 3), -6, 7)
+    temp0 = np.full((3, n), 1e10, np.float32)
+    temp0[1] = rng.uniform(0.5, 50.0, n).astype(np.float32)           # caller-provided start values for one cloud
+    pts = dev(xyz)
+    t_ref = dev(temp0.copy()); i_ref = torch.zeros((3, m), dtype=torch.int32, device="cuda")
+    C.farthest_point_sampling_wrapper(3, n, m, pts, t_ref, i_ref)
+    t1 = dev(temp0.copy()); i1 = torch.zeros_like(i_ref)
+    C.farthest_point_sampling_pruned_wrapper(3, n, m, pts, t1, i1)
+    assert torch.equal(i1, i_ref) and torch.equal(t1, t_ref)
+    perm = torch.stack([torch.randperm(n, device="cuda") for _ in range(3)]).int().contiguous()
+    t2 = dev(temp0.copy()); i2 = torch.zeros_like(i_ref)
+    L.call("mgar_fps_batch_perm", 3, n, m, L.fptr(pts), L.fptr(t2), L.iptr(perm), L.iptr(i2), L.stream_of(pts))
+    assert torch.equal(i2, i_ref) and torch.equal(t2, t_ref)
+
+
+def test_fps_pruned_rejects_out_of_range_sizes():
+    from multimodal_gar_amd import _lib as L
+    pts = torch.zeros(1, 500, 3, device="cuda"); t = torch.zeros(1, 500, device="cuda")
+    perm = torch.arange(500, device="cuda").int().view(1, -1); idx = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
+    with pytest.raises(L.MgarError):
+        L.call("mgar_fps_batch_perm", 1, 500, 4, L.fptr(pts), L.fptr(t), L.iptr(perm), L.iptr(idx), L.stream_of(pts))
+
+
 def test_fps_stream_fallback_large_cloud(ops, oracle):
     pb = ops[0]
     xyz = scene_xyz(99, 1, 20000)
