@@ -322,7 +322,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(FpsArgs A, const int *
         const float ex = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.f), ey = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.f);
         const float ez = fmaxf(fmaxf(bz0 - z1, z1 - bz1), 0.f);
         const float dmin2 = (ex * ex + ey * ey + ez * ez) * 0.99999f;
-        if (dmin2 < c_best) {  // wave-uniform: some point of this wave may move
+        if (j == 1 || dmin2 < c_best) {  // wave-uniform: some point of this wave may move (round 1: everybody publishes)
             float best = -1.f;
             int bslot = 0, bprio = 0x7FFFFFFF;
             const typename VecOf<PPT>::f dx = X - x1, dy = Y - y1, dz = Z - z1;
