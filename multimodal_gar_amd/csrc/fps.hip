@@ -316,6 +316,7 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(FpsArgs A, const int *
     if (tid == 0) out[0] = 0;
 
     float c_best = inf;   // max D over the wave as of its last update (wave-uniform); +inf = never updated
+    bool other_stale = false;   // slots[] is double-buffered: after an update the other buffer still holds the old record
 
     for (int j = 1; j < m; ++j) {
         FpsSlot *buf = slots[j & 1];
@@ -351,8 +352,10 @@ __global__ __launch_bounds__(1024) void fps_pruned_kernel(FpsArgs A, const int *
             // the wave maximum is the high word of the key: invert ordered_bits
             const unsigned ob = (unsigned)(wkey >> 32);
             c_best = __uint_as_float(ob ^ ((ob >> 31) ? 0x80000000u : 0xFFFFFFFFu));
-        } else if (lane == 0) {
-            buf[wave] = cached[wave];
+            other_stale = true;
+        } else if (other_stale) {  // first skipped round after an update: bring the other buffer up to date, once
+            if (lane == 0) buf[wave] = cached[wave];
+            other_stale = false;
         }
         __syncthreads();
         // ---- 16-lane reduction over the per-wave slots (every row does the same) ----
