@@ -52,6 +52,9 @@ def parse():
                     help="do not use MIOpen find mode (torch.backends.cudnn.benchmark) for the I3D convolutions; with it the "
                          "solver choice comes from multimodal_gar_amd/miopen_db (24 %% faster I3D than immediate mode)")
     ap.add_argument("--no-overlap", action="store_true", help="run the RGB and LiDAR branches on one stream")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward + backward from a HIP graph (torch.cuda.CUDAGraph); data parallelism then is one "
+                         "flattened gradient all-reduce after the replay instead of DistributedDataParallel")
     ap.add_argument("--phases", action="store_true", help="print a synchronised per-phase timing of one step")
     return ap.parse_args()
 
@@ -72,7 +75,7 @@ def kernel_rooflines(step, batch, frames, n_points):
     from multimodal_gar_amd import _lib as L
     L.kernel_timers(enable=True)
     L.kernel_timers()                       # drop anything recorded so far
-    step.run(batch)
+    step.run_eager(batch)
     torch.cuda.synchronize()
     L.kernel_timers(enable=False)
     table = L.kernel_timers()
@@ -193,7 +196,8 @@ def main():
     from multimodal_gar_amd import workload as W
     torch.backends.cudnn.benchmark = not args.no_miopen_find   # MIOpen find mode for the I3D convolutions
     log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
-    step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp)
+    step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp,
+                       manual_allreduce=args.graph)
     step.module.overlap_branches = not args.no_overlap   # frozen I3D on a side stream (no autograd there: DDP-safe)
     batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
 
@@ -206,6 +210,9 @@ def main():
     if args.phases and rank == 0 and not ddp:
         phase_timing(step, batch)
         phase_timing(step, batch)
+    if args.graph:
+        step.capture(batch)
+        log("forward + backward captured into a HIP graph")
     for i in range(args.warmup):
         step.run(batch); torch.cuda.synchronize(); log("warmup step %d done" % i)
     barrier()
@@ -233,7 +240,7 @@ def main():
             log("dominant hand-written kernel: %s, %.2f ms/step in %d launches, %.0f %s (%.1f %% of peak)"
                 % (roof["kernel"], roof["ms_per_step"], roof["launches_per_step"], roof["achieved"], roof["unit"], 100 * roof["frac"]))
         else:
-            step.run(batch)          # the extra (instrumented on rank 0) step is collective under DDP
+            step.run_eager(batch)    # the extra (instrumented on rank 0) step is collective under DDP
         barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)

@@ -103,7 +103,17 @@ class GATv2Conv(nn.Module):
         n = x.shape[0]
         xl = self.lin_l(x)
         xr = xl if self.share_weights else self.lin_r(x)
-        rowptr, col = edges_to_csr(edge_index, n, self.add_self_loops)
+        # the CSR form depends only on the edge list: keep it on the tensor object (edge lists of fully connected
+        # scenes are cached by the caller), which also keeps the boolean-mask / bincount host syncs out of the step
+        cached = getattr(edge_index, "_mgar_csr", None)
+        if cached is not None and cached[0] == (n, self.add_self_loops, edge_index._version):
+            rowptr, col = cached[1]
+        else:
+            rowptr, col = edges_to_csr(edge_index, n, self.add_self_loops)
+            try:
+                edge_index._mgar_csr = ((n, self.add_self_loops, edge_index._version), (rowptr, col))
+            except (AttributeError, RuntimeError):
+                pass
         edge_scale = None
         if self.training and self.dropout > 0:
             keep = 1.0 - self.dropout

@@ -346,11 +346,22 @@ class RGB_Backbone(nn.Module):
         return boxes_features
 
 
+_EDGE_CACHE = {}
+
+
 def fully_connected_edges(boxes_len, device):
-    """All ordered pairs i != j inside each scene (combinations + flip, reference :1085-1092)."""
-    per_scene = [torch.combinations(torch.arange(0, n) + sum(boxes_len[:max(0, i)]), r=2) for i, n in enumerate(boxes_len)]
-    pairs = torch.cat(per_scene, 0)
-    return torch.cat((pairs, torch.flip(pairs, [1])), 0).T.to(device)
+    """All ordered pairs i != j inside each scene (combinations + flip, reference :1085-1092).  The result only
+    depends on the scene sizes, so it is built once per (sizes, device) and reused (no host->device copy per call;
+    graph_ops caches its CSR form on the tensor)."""
+    key = (tuple(int(n) for n in boxes_len), str(device))
+    edges = _EDGE_CACHE.get(key)
+    if edges is None:
+        per_scene = [torch.combinations(torch.arange(0, n) + sum(boxes_len[:max(0, i)]), r=2) for i, n in enumerate(boxes_len)]
+        pairs = torch.cat(per_scene, 0)
+        edges = torch.cat((pairs, torch.flip(pairs, [1])), 0).T.contiguous().to(device)
+        if len(_EDGE_CACHE) < 64:
+            _EDGE_CACHE[key] = edges
+    return edges
 
 
 def _head(in_dim, out_dim, final, bn=False):

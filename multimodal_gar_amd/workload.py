@@ -197,8 +197,9 @@ class ClipModel(nn.Module):
                 crops = self.rgb_crops(batch["images"], batch["bboxes"])
             lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], new_xyz1)   # (B*T, A, 512)
             main.wait_stream(self._side_stream)
-            for c in crops:
-                c.record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():   # inside a graph the pool is private and replays are serial
+                for c in crops:
+                    c.record_stream(main)
             rgb = self.rgb_tokens_from_crops(crops)                                   # (B, A, 512)
         else:
             rgb = self.rgb_tokens(batch["images"], batch["bboxes"])
@@ -246,28 +247,94 @@ def synthetic_loss(outputs):
 
 
 class TrainStep:
-    """model + Adam + (optional) DDP; ``run(batch)`` = forward, loss, backward, optimizer step."""
+    """model + Adam + data parallelism; ``run(batch)`` = forward, loss, backward, (gradient all-reduce,) optimizer step.
 
-    def __init__(self, n_actors, n_points, device, gat=True, route="pointnet2", ddp=False, lr=1e-3, seed=2023):
+    ddp=True wraps the model in DistributedDataParallel (bucketed all-reduce overlapped with backward).
+    ``capture(batch)`` records forward + backward of one step into a HIP graph (torch.cuda.CUDAGraph): the ~1 900-
+    4 700 launches of a step are replayed without the host, which is what bounds a rank that holds a single clip.
+    In graph mode the data-parallel exchange is ONE all-reduce of the flattened gradients after the replay
+    (no DDP wrapper: its hooks cannot live inside a captured backward), then Adam."""
+
+    def __init__(self, n_actors, n_points, device, gat=True, route="pointnet2", ddp=False, lr=1e-3, seed=2023,
+                 manual_allreduce=False):
         torch.manual_seed(seed)  # the reference seeds 2023 (train_func.py:45-47)
         self.model = ClipModel(n_actors, n_points, gat, route).to(device)
         self.model.train()
         self.module = self.model
-        if ddp:
+        self.manual_allreduce = bool(manual_allreduce)
+        if ddp and not manual_allreduce:
             from torch.nn.parallel import DistributedDataParallel as DDP
             dev_ids = [device.index] if device.type == "cuda" else None
             self.model = DDP(self.model, device_ids=dev_ids, find_unused_parameters=False, gradient_as_bucket_view=True,
                              bucket_cap_mb=64)
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        self.opt = torch.optim.Adam(params, lr=lr)   # train_func.py:552 Adam(lr=1e-3)
+        self.params = [p for p in self.model.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(self.params, lr=lr)   # train_func.py:552 Adam(lr=1e-3)
+        self.graph = None
+        self._static_batch = None
+        self._loss = None
 
-    def run(self, batch):
+    # ---- eager step ------------------------------------------------------------------------------
+    def _forward_backward(self, batch):
         self.opt.zero_grad(set_to_none=True)
         out = self.model(batch)
         loss = synthetic_loss(out)
         loss.backward()
-        self.opt.step()
         return loss.detach()
+
+    def _exchange_gradients(self):
+        """One all-reduce(SUM)/world over all gradients, flattened (~119 MB fp32 per step)."""
+        if not self.manual_allreduce:
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        grads = [p.grad for p in self.params if p.grad is not None]
+        flat = torch._utils._flatten_dense_tensors(grads)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+        for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+            g.copy_(f)
+
+    def run_eager(self, batch):
+        loss = self._forward_backward(batch)
+        self._exchange_gradients()
+        self.opt.step()
+        return loss
+
+    # ---- HIP-graph step ---------------------------------------------------------------------------
+    def capture(self, batch, warmup=2):
+        """Record forward + backward on ``batch`` (its tensors become the static inputs: later batches are copied
+        into them).  `warmup` eager steps run first on a side stream, as graph capture requires."""
+        assert self.graph is None and batch["images"].is_cuda
+        assert not hasattr(self.model, "module") or self.model is self.module, "capture() needs manual_allreduce, not DDP"
+        self._static_batch = batch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.run_eager(batch)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.model(batch)
+            loss = synthetic_loss(out)
+            loss.backward()
+        self.graph, self._loss = graph, loss.detach()
+        return self
+
+    def run(self, batch):
+        if self.graph is None:
+            return self.run_eager(batch)
+        if batch is not self._static_batch:
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    self._static_batch[k].copy_(v)
+        self.graph.replay()
+        self._exchange_gradients()
+        self.opt.step()
+        return self._loss
 
 
 def trainable_parameter_count(module):

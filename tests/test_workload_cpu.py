@@ -53,7 +53,7 @@ def _free_port():
     return p
 
 
-def _ddp_worker(rank, world, port, out_path):
+def _ddp_worker(rank, world, port, out_path, manual=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -63,14 +63,18 @@ def _ddp_worker(rank, world, port, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     with use_cpu_oracle():
-        step = W.TrainStep(3, 256, dev, ddp=True, seed=5)
+        step = W.TrainStep(3, 256, dev, ddp=True, seed=5, manual_allreduce=manual)
         _no_dropout(step.module)
         full = W.make_batch(11, world, 1, 3, 256, 32, 48, dev)            # the GLOBAL batch: `world` clips
         mine = {k: (v[rank:rank + 1] if torch.is_tensor(v) else v) for k, v in full.items()}
         mine["n_clips"] = 1
-        step.opt.zero_grad(set_to_none=True)
-        loss = W.synthetic_loss(step.model(mine))
-        loss.backward()
+        if manual:       # the graph-mode exchange: one all-reduce of the flattened gradients after backward
+            step._forward_backward(mine)
+            step._exchange_gradients()
+        else:
+            step.opt.zero_grad(set_to_none=True)
+            loss = W.synthetic_loss(step.model(mine))
+            loss.backward()
     if rank == 0:
         g = {n: p.grad.clone() for n, p in step.module.named_parameters() if p.grad is not None}
         torch.save(g, out_path)
@@ -78,12 +82,15 @@ def _ddp_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_ddp_gloo_world2_matches_single_process(tmp_path):
+@pytest.mark.parametrize("manual", [False, True])
+def test_ddp_gloo_world2_matches_single_process(tmp_path, manual):
+    """DistributedDataParallel (manual=False) and the flattened manual all-reduce of the HIP-graph mode (manual=True)
+    against a single process on the same global batch."""
     import torch.multiprocessing as mp
     from multimodal_gar_amd import workload as W
     from oracle.cpu_backend import use_cpu_oracle
     out_path = str(tmp_path / "ddp_grads.pt")
-    mp.spawn(_ddp_worker, args=(2, _free_port(), out_path), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out_path, manual), nprocs=2, join=True)
     ddp_grads = torch.load(out_path)
     dev = torch.device("cpu")
     # same thread count as the workers: the tiny I3D feature maps make BatchNorm statistics
