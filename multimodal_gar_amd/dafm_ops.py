@@ -36,15 +36,26 @@ class _DafmAttention(Function):
         return gq, gk, gv, None, None, None, None, None
 
 
+_OFFSET_CACHE = {}
+
+
 def scene_offsets(counts, device):
-    """counts: python list of actors per scene -> (scene_off (S+1,), de_off (S,)) int32 on device."""
+    """counts: python list of actors per scene -> (scene_off (S+1,), de_off (S,)) int32 on device.
+    Cached per (counts, device): no host->device copy in the steady state (and none under graph capture)."""
+    key = (tuple(int(c) for c in counts), str(device))
+    hit = _OFFSET_CACHE.get(key)
+    if hit is not None:
+        return hit
     so, do, r, m = [0], [], 0, 0
     for n in counts:
         do.append(m)
         r += n
         m += n * n
         so.append(r)
-    return (torch.tensor(so, dtype=torch.int32, device=device), torch.tensor(do, dtype=torch.int32, device=device))
+    out = (torch.tensor(so, dtype=torch.int32, device=device), torch.tensor(do, dtype=torch.int32, device=device))
+    if len(_OFFSET_CACHE) < 64:
+        _OFFSET_CACHE[key] = out
+    return out
 
 
 def dafm_attention(q, k, v, de_flat, scene_off, de_off, sigma, scale):
