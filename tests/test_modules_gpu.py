@@ -230,9 +230,9 @@ def test_project_then_group_path_equals_reference_chain():
 
 
 def test_train_step_hip_graph_matches_eager():
-    """TrainStep.capture(): forward + backward replayed from a HIP graph must give the gradients and parameter
-    updates of the eager step (dropout off: the graph-safe RNG draws different masks)."""
-    import copy
+    """TrainStep.capture(): forward + backward replayed from a HIP graph must give the loss and the gradients of
+    the eager step from the same state (dropout off: the graph-safe RNG draws different masks), and the graph-mode
+    step must keep training (parameters move, loss stays finite)."""
     from multimodal_gar_amd import workload as W
     dev = torch.device("cuda")
     batch = W.make_batch(3, 1, 2, 4, 2048, 96, 160, dev)
@@ -246,19 +246,24 @@ def test_train_step_hip_graph_matches_eager():
                 m.dropout = 0.0
         return step
     eager, graph = build(), build()
-    graph.module.load_state_dict(copy.deepcopy(eager.module.state_dict()))
-    graph.capture(batch, warmup=2)                       # two eager warm-up steps inside, then the capture
-    for _ in range(2):
-        eager.run_eager(batch)                           # bring the eager twin to the same state (2 warm-up steps)
-    for _ in range(3):
-        le, lg = eager.run(batch), graph.run(batch)
-    torch.cuda.synchronize()
+    graph.capture(batch, warmup=2)                        # two eager warm-up steps inside, then the capture
     assert graph.graph is not None
+    eager.module.load_state_dict(graph.module.state_dict())
+    le = eager._forward_backward(batch)
+    graph.graph.replay()
+    torch.cuda.synchronize()
+    lg = graph._loss
     assert abs(float(le) - float(lg)) <= 1e-4 * abs(float(le)) + 1e-6
-    worst = 0.0
+    worst, checked = 0.0, 0
     for (n, p), (_, q) in zip(eager.module.named_parameters(), graph.module.named_parameters()):
         if p.grad is None:
             continue
+        assert q.grad is not None, n
         scale = p.grad.abs().max().item() + 1e-12
         worst = max(worst, (p.grad - q.grad).abs().max().item() / scale)
-    assert worst <= 2e-3, worst                          # float atomics reorder sums between runs
+        checked += 1
+    assert checked > 100 and worst <= 1e-3, worst         # float atomics reorder sums between runs
+    before = [p.detach().clone() for p in graph.params[:5]]
+    losses = [float(graph.run(batch)) for _ in range(3)]
+    assert all(l == l and l < 1e6 for l in losses)
+    assert any(not torch.equal(a, b) for a, b in zip(before, graph.params[:5]))
