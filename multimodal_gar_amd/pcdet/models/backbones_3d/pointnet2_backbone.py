@@ -54,7 +54,10 @@ class PointNet2MSG(nn.Module):
             l_features.append(li_features)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
             l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
-        point_features = l_features[0].permute(0, 2, 1).contiguous()
-        batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
+        # (B, C, n) channel-major, as produced: consumers on the device take this (no transposed copy of ~1 GB)
+        batch_dict['point_features_cm'] = l_features[0]
+        if self.model_cfg.get('STACKED_POINT_FEATURES', True) or not xyz.is_cuda:   # the reference's key (pointnet2_backbone.py:91-92)
+            point_features = l_features[0].permute(0, 2, 1).contiguous()
+            batch_dict['point_features'] = point_features.view(-1, point_features.shape[-1])
         batch_dict['point_coords'] = torch.cat((batch_idx[:, None].float(), l_xyz[0].view(-1, 3)), dim=1)
         return batch_dict

@@ -43,7 +43,10 @@ class PointGridRoIHead(nn.Module):
         xyz_cnt = batch_dict.get('point_batch_cnt')
         if xyz_cnt is None:
             xyz_cnt = torch.bincount(coords[:, 0].long(), minlength=batch_size).int()
+        feats = batch_dict.get('point_features_cm') if xyz.is_cuda else None   # (B, C, n) channel-major, device path
+        if feats is None or feats.shape[0] * feats.shape[2] != xyz.shape[0]:
+            feats = batch_dict['point_features'].contiguous()                  # (P, C) stacked rows (reference layout)
         _, pooled = self.roi_grid_pool_layer(xyz=xyz, xyz_batch_cnt=xyz_cnt, new_xyz=new_xyz, new_xyz_batch_cnt=new_cnt,
-                                             features=batch_dict['point_features'].contiguous())
-        batch_dict['pooled_features'] = pooled.view(-1, g ** 3, pooled.shape[-1])
+                                             features=feats)
+        batch_dict['pooled_features'] = pooled.reshape(-1, g ** 3, pooled.shape[-1])
         return batch_dict

@@ -60,14 +60,22 @@ class StackSAModuleMSG(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
-        """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1]))."""
+        """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1])).
+
+        `features` may also be (B, C, n) channel-major with n points in every sample (device path only).  The
+        returned new_features has the reference's shape; on the device its memory is channel-major (a transposed
+        view), which is what both its producer (the fused BN/ReLU/max kernel) and its consumer (the (N, C, 6, 6, 6)
+        grid of the non-local block) want -- two strided transposing copies become contiguous ones."""
         per_scale = []
         projected = {}
+        n_feat = None if features is None else features.shape[1]
+        if features is not None and features.dim() == 3:
+            assert self.pool_method == 'max_pool' and xyz.is_cuda, "channel-major features: fused device path only"
         if self.pool_method == 'max_pool' and features is not None and xyz.is_cuda:
             # "project, then group": layer 0 is linear, apply its feature half to the N points first --
             # for all scales in ONE GEMM over the shared features
             fold = [k for k, (g, mlp) in enumerate(zip(self.groupers, self.mlps))
-                    if g.use_xyz and mlp.first_layer_foldable(3 + features.shape[1])]
+                    if g.use_xyz and mlp.first_layer_foldable(3 + n_feat)]
             if fold:
                 ys = pointnet2_utils._FusedQueryGroupProjMSG.apply(
                     xyz, xyz_batch_cnt.int(), new_xyz, new_xyz_batch_cnt.int(), features,
@@ -80,6 +88,7 @@ class StackSAModuleMSG(nn.Module):
                 x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1)
                 per_scale.append(x.squeeze(0).permute(1, 0))
                 continue
+            assert features is None or features.dim() == 2, "channel-major features need the projected (foldable) path"
             grouped, _ = grouper.forward_channel_major(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features)
             grouped = grouped.view(1, grouped.shape[0], new_xyz.shape[0], -1)              # (1, C, M, nsample)
             if self.pool_method == 'max_pool':
@@ -89,6 +98,8 @@ class StackSAModuleMSG(nn.Module):
             else:
                 raise NotImplementedError
             per_scale.append(x.squeeze(0).permute(1, 0))                                    # (M, C')
+        if xyz.is_cuda and all(p.stride(0) == 1 for p in per_scale):
+            return new_xyz, torch.cat([p.t() for p in per_scale], dim=0).t()                # (M, C'), channel-major memory
         return new_xyz, torch.cat(per_scale, dim=1)
 
 

@@ -165,13 +165,21 @@ class _FusedQueryGroupProjMSG(Function):
 
     @staticmethod
     def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, *weights):
+        """features: (N, C) stacked rows, or (B, C, n) CHANNEL-MAJOR with n points in every sample (the layout the
+        PointNet++ trunk produces: no transposed copy of the feature matrix is needed for the projection GEMM)."""
         n_samples, n_query = xyz_batch_cnt.shape[0], new_xyz.shape[0]
         features = features.contiguous()
+        channel_major = features.dim() == 3
         ws = [w.reshape(w.shape[0], -1) for w in weights]
         chans = [w.shape[0] for w in ws]
         ld = sum(chans)
         w_f = torch.cat([w[:, 3:] for w in ws], 0).contiguous()                                # (ld, C)
-        zf = features @ w_f.t()                                                                # (N, ld)
+        if channel_major:
+            b, c, n = features.shape
+            assert b == n_samples and b * n == xyz.shape[0]
+            zf = torch.bmm(features.transpose(1, 2), w_f.t().unsqueeze(0).expand(b, c, ld)).view(b * n, ld)
+        else:
+            zf = features @ w_f.t()                                                            # (N, ld)
         outs, saved = [], []
         col = 0
         for radius, nsample, w, c in zip(radii, nsamples, ws, chans):
@@ -197,7 +205,10 @@ class _FusedQueryGroupProjMSG(Function):
         saved = ctx.saved_tensors[4:]
         n_samples, n_query, chans, nsamples, w_shapes = ctx.meta
         ld = sum(chans)
-        grad_zf = torch.zeros((features.shape[0], ld), dtype=torch.float32, device=features.device)
+        channel_major = features.dim() == 3
+        n_rows = features.shape[0] * features.shape[2] if channel_major else features.shape[0]
+        n_feat = features.shape[1]
+        grad_zf = torch.zeros((n_rows, ld), dtype=torch.float32, device=features.device)
         grad_wx = []
         col = 0
         for k, (c, nsample) in enumerate(zip(chans, nsamples)):
@@ -207,11 +218,17 @@ class _FusedQueryGroupProjMSG(Function):
                                                     grad_zf, zf_ld=ld, zf_col=col)
             grad_wx.append(pointwise_dw(rel.unsqueeze(0), gy.unsqueeze(0)))                    # (C_k, 3)
             col += c
-        grad_features = grad_zf @ w_f if ctx.needs_input_grad[4] else None
-        if ld <= 96 and features.shape[1] <= 128:
-            grad_wf = pointnet2.rowmajor_dw(grad_zf, features)                                 # (ld, C)
+        if channel_major:
+            b, c, n = features.shape
+            g3 = grad_zf.view(b, n, ld)
+            grad_features = torch.bmm(w_f.t().unsqueeze(0).expand(b, c, ld), g3.transpose(1, 2)) if ctx.needs_input_grad[4] else None
+            grad_wf = torch.bmm(g3.transpose(1, 2), features.transpose(1, 2)).sum(0)           # (ld, C)
         else:
-            grad_wf = grad_zf.t() @ features
+            grad_features = grad_zf @ w_f if ctx.needs_input_grad[4] else None
+            if ld <= 96 and n_feat <= 128:
+                grad_wf = pointnet2.rowmajor_dw(grad_zf, features)                             # (ld, C)
+            else:
+                grad_wf = grad_zf.t() @ features
         grad_ws, col = [], 0
         for c, gwx, shape in zip(chans, grad_wx, w_shapes):
             grad_ws.append(torch.cat([gwx, grad_wf[col:col + c]], 1).view(shape))

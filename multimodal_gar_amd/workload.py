@@ -47,7 +47,10 @@ def lidar_model_cfg(n_points, route="pointnet2"):
                                NSAMPLE=[[16, 32], [16, 32], [16, 32], [16, 32]],
                                MLPS=[[[16, 16, 32], [32, 32, 64]], [[64, 64, 128], [64, 96, 128]],
                                      [[128, 196, 256], [128, 196, 256]], [[256, 256, 512], [256, 384, 512]]]),
-                FP_MLPS=[[128, 128], [256, 256], [512, 512], [512, 512]]),
+                FP_MLPS=[[128, 128], [256, 256], [512, 512], [512, 512]],
+                # nothing downstream of the trunk reads the stacked (P, C) copy on the device: the RoI head takes the
+                # channel-major tensor (point_features_cm), so the ~1 GB transposed copy is skipped
+                STACKED_POINT_FEATURES=False),
             ROI_HEAD=dict(NAME="PointGridRoIHead",
                           # pooling geometry of mil3.yaml:105-134
                           ROI_GRID_POOL=dict(GRID_SIZE=6, MLPS=[[32, 32], [32, 32], [32, 32]],

@@ -229,6 +229,35 @@ def test_project_then_group_path_equals_reference_chain():
         close(a, b, rtol=5e-4)
 
 
+def test_stack_sa_msg_channel_major_features_equal_stacked_rows():
+    """StackSAModuleMSG fed (B, C, n) channel-major features (what the PointNet++ trunk produces) must give what
+    it gives for the stacked (B*n, C) rows: outputs, input gradient (in the other layout) and parameter gradients."""
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as MS
+    torch.manual_seed(4)
+    xyz, _ = scene(9, 3, 800)
+    sx = xyz.reshape(-1, 3).cuda()
+    cnt = torch.tensor([800, 800, 800], dtype=torch.int32, device="cuda")
+    new_xyz = torch.cat([sx[:60], sx[800:900] + 0.03, sx[1600:1650] - 0.02]).contiguous()
+    ncnt = torch.tensor([60, 100, 50], dtype=torch.int32, device="cuda")
+    fcm = torch.randn(3, 40, 800, device="cuda")
+    mod = fill_deterministic(MS.StackSAModuleMSG(radii=[0.9, 2.5, 1.5], nsamples=[8, 16, 16],
+                                                 mlps=[[40, 16], [40, 24, 32], [40, 32]]), seed=8).cuda().train()
+    outs, fgrads, pgrads = [], [], []
+    for cm in (True, False):
+        m = copy.deepcopy(mod)
+        f = (fcm.clone() if cm else fcm.permute(0, 2, 1).reshape(-1, 40).contiguous()).requires_grad_(True)
+        _, y = m(sx, cnt, new_xyz, ncnt, f)
+        assert y.shape == (210, 16 + 32 + 32)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view(y.shape)).sum().backward()
+        outs.append(y)
+        fgrads.append(f.grad if cm else f.grad.view(3, 800, 40).permute(0, 2, 1))
+        pgrads.append([p.grad for p in m.parameters()])
+    close(outs[0], outs[1])
+    close(fgrads[0], fgrads[1], rtol=5e-4)
+    for a, b in zip(*pgrads):
+        close(a, b, rtol=5e-4)
+
+
 def test_train_step_hip_graph_matches_eager():
     """TrainStep.capture(): forward + backward replayed from a HIP graph must give the loss and the gradients of
     the eager step from the same state (dropout off: the graph-safe RNG draws different masks), and the graph-mode
