@@ -66,8 +66,9 @@ def parse():
 # Live timing of the hand-written kernels: the library brackets each instrumented kernel launch with
 # two HIP events recorded on the stream the kernel is launched on (csrc/errors.hip, mgar_ktimer_*) and
 # notes the launch's algorithmic bytes / flops.  The timers
-# are switched on for ONE extra step of the same workload right after the timed region, so the headline
-# number is not perturbed by ~3 000 event records per step.
+# are switched on for ONE extra step of the same workload right after the timed region -- issued eagerly on a
+# single stream, so that every kernel has the chip to itself between its two events -- and the headline number
+# is not perturbed by ~3 000 event records per step.
 # --------------------------------------------------------------------------------------------
 MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel")
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # rocprofv3 --pmc passes, see profiles/README.md
@@ -76,11 +77,15 @@ PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # ro
 def kernel_rooflines(step, batch, frames, n_points):
     """-> list of per-kernel roofline dicts for one training step, the dominant (largest total time) first."""
     from multimodal_gar_amd import _lib as L
+    # one stream for this step: with the RGB branch on its side stream two kernels share the chip and the time
+    # between a kernel's two events is no longer the time that kernel needs
+    overlap, step.module.overlap_branches = step.module.overlap_branches, False
     L.kernel_timers(enable=True)
     L.kernel_timers()                       # drop anything recorded so far
     step.run_eager(batch)
     torch.cuda.synchronize()
     L.kernel_timers(enable=False)
+    step.module.overlap_branches = overlap
     table = L.kernel_timers()
     traffic = {}
     if os.path.exists(PMC_TRAFFIC_FILE):
