@@ -24,7 +24,7 @@ KERNELS = {
     "bn_max_bwd_partial_kernel": "mgar::bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel": "mgar::bn_max_bwd_apply_kernel",
     "pointwise_fwd_kernel": "mgar::pointwise_fwd_kernel", "pointwise_dw_kernel": "mgar::pointwise_dw_kernel<",
     "rowmajor_dw_kernel": "mgar::rowmajor_dw_kernel", "maxpool3d_same_kernel": "mgar::maxpool3d_same",
-    "fps_kernel": "mgar::fps_kernel", "ball_query_kernel": "mgar::ball_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
+    "fps_kernel": "mgar::fps_", "ball_query_kernel": "mgar::ball_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
     "three_interp_fwd": "mgar::three_interp_batch_fwd", "three_interp_bwd": "mgar::three_interp_batch_bwd",
     "query_group_fwd": "_fwd_kernel(int, int, int, int, float const*", "query_group_bwd": "mgar::qg_",
 }
