@@ -245,6 +245,15 @@ int mgar_bn_workspace_floats(int B, int C, int P);
 int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace,
                         float *mean, float *invstd, float *running_mean, float *running_var,
                         long long *num_batches_tracked, void *stream);
+/* Per-sample statistics: each of the G samples of x (G,C,P) is normalised with ITS OWN batch statistics
+ * (mean / invstd have G*C entries) -- what the reference computes when it sends G clips through a train-mode
+ * BatchNorm one at a time (I3D, model/gat_model.py:1048) -- and the running statistics receive the G momentum
+ * updates in sample order.  workspace: mgar_bn_workspace_floats(1, G*C, P) floats.  Forward only. */
+int mgar_bn_train_stats_grouped(const float *x, int G, int C, int P, float eps, float momentum, float *workspace,
+                                float *mean, float *invstd, float *running_mean, float *running_var,
+                                long long *num_batches_tracked, void *stream);
+int mgar_bn_act_fwd_grouped(const float *x, int G, int C, int P, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean,

@@ -58,6 +58,8 @@ _PROTOS = {
     "mgar_rowmajor_dw": [_P, _I, _P, _I, _LL, _I, _I, _P, _P, _P],
     "mgar_bn_workspace_floats": [_I, _I, _I],
     "mgar_bn_train_stats": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_bn_train_stats_grouped": [_P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_bn_act_fwd_grouped": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],

@@ -176,6 +176,33 @@ def bn_act(x, bn, relu):
     return _BnAct.apply(x3, gamma, beta, mean, invstd, relu).view(x.shape)
 
 
+def bn_act_per_sample(x, bn, relu):
+    """[relu](bn(x)) where every sample of x (G, C, ...) is normalised with its own batch statistics and the running
+    statistics get the G momentum updates in sample order: G clips through a train-mode BatchNorm in ONE pass, with
+    the result of feeding them one at a time.  Forward only (frozen I3D); None if that does not apply."""
+    if not (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() >= 3) or (torch.is_grad_enabled() and
+                                                                                        (x.requires_grad or bn.weight.requires_grad)):
+        return None
+    x3 = x.contiguous().flatten(2)
+    g, c, p = x3.shape
+    if g * c > 65535:
+        return None
+    mean = torch.empty((g * c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    track = bn.track_running_stats and bn.running_mean is not None
+    ws = _workspace(x3, 1, g * c, p)
+    st = L.stream_of(x3)
+    L.call("mgar_bn_train_stats_grouped", L.fptr(x3), g, c, p, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
+           L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
+           L.fptr(bn.running_var) if track else None,
+           L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None, st)
+    gamma, beta = _affine(bn, c, x.device)
+    y = torch.empty_like(x3)
+    L.call("mgar_bn_act_fwd_grouped", L.fptr(x3), g, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), int(relu),
+           L.fptr(y), st)
+    return y.view(x.shape)
+
+
 def bn_act_maxpool(x, bn, relu):
     """max over the last axis of [relu](bn(x)) for x (B, C, M, ns) -> (B, C, M)."""
     x4 = x.contiguous()

@@ -85,7 +85,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float eps,
                                                          float momentum, float *__restrict__ mean, float *__restrict__ invstd,
                                                          float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                         long long *__restrict__ num_batches_tracked) {
+                                                         long long *__restrict__ num_batches_tracked,
+                                                         float *__restrict__ var_out) {
     const int c = blockIdx.x;
     double s = 0.0, q = 0.0;
     for (int i = threadIdx.x; i < nchunk; i += 64) {
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (var_out) var_out[c] = (float)var;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
     if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(n > 1.0 ? var * n / (n - 1.0) : var);
     if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
@@ -113,11 +115,12 @@ template <bool RELU>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__restrict__ x, int C, int P,
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                              float *__restrict__ y) {
+                                                              float *__restrict__ y, int stats_per_row) {
     const int row = blockIdx.x;
     const int c = row % C;
-    const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const int sidx = stats_per_row ? row : c;   // per-sample statistics: mean / invstd have one entry per (sample, channel)
+    const float sc = invstd[sidx] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[sidx] * sc;
     const float *xr = x + (size_t)row * P;
     float *yr = y + (size_t)row * P;
     const int base = blockIdx.y * (BN_THREADS * 4 * BN_APPLY_V);
@@ -410,7 +413,7 @@ using namespace mgar;
 BN_API int mgar_bn_workspace_floats(int B, int C, int P) {
     if (B < 0 || C < 0 || P < 0) return MGAR_EINVAL;
     const int nc = bn_nchunk_fwd(B, C, P) > bn_nchunk(B, P) ? bn_nchunk_fwd(B, C, P) : bn_nchunk(B, P);
-    return 2 * C * (nc > 0 ? nc : 1) + 2 * C;
+    return 2 * C * (nc > 0 ? nc : 1) + 2 * C;   // [partials | 2*C: bwd coefficients, or C: variances of the grouped statistics]
 }
 
 static int bn_sizes_ok(int B, int C, long long P) { return B >= 0 && C >= 0 && P >= 0 && (long long)B * C <= 2147483647LL; }
@@ -428,7 +431,7 @@ BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, f
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, chunk, workspace);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, eps,
-                       momentum, mean, invstd, running_mean, running_var, num_batches_tracked);
+                       momentum, mean, invstd, running_mean, running_var, num_batches_tracked, (float *)nullptr);
     return check_launch("bn_train_stats: launch failed");
 }
 
@@ -441,10 +444,66 @@ BN_API int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mea
     dim3 grid(B * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_APPLY, st, 8.0 * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y);
+    if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 0);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 0);
     }
     return check_launch("bn_act_fwd: launch failed");
+}
+
+// ---- per-sample ("grouped") statistics: G samples, each normalised with its OWN batch statistics -------------
+// = what the reference computes when it pushes G clips through a train-mode BatchNorm one at a time (I3D: one pass
+// per clip), but as one launch over the (G, C, P) tensor.  The running statistics receive the G momentum updates
+// in sample order.
+__global__ void bn_running_update_grouped_kernel(const float *__restrict__ mean, const float *__restrict__ var, int G, int C,
+                                                 double n, float momentum, float *__restrict__ running_mean,
+                                                 float *__restrict__ running_var, long long *__restrict__ num_batches_tracked) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += G;
+    if (c >= C) return;
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        rm = (1.f - momentum) * rm + momentum * mean[(size_t)g * C + c];
+        const double v = (double)var[(size_t)g * C + c];
+        rv = (1.f - momentum) * rv + momentum * (float)(n > 1.0 ? v * n / (n - 1.0) : v);
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+}
+
+BN_API int mgar_bn_train_stats_grouped(const float *x, int G, int C, int P, float eps, float momentum, float *workspace,
+                                       float *mean, float *invstd, float *running_mean, float *running_var,
+                                       long long *num_batches_tracked, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(G, C, P), "bn_train_stats_grouped: bad sizes");
+    if ((long long)G * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && workspace && mean && invstd, "bn_train_stats_grouped: null pointer");
+    const int rows = G * C;   // every (sample, channel) row is its own "channel" of a batch of one
+    MGAR_REQUIRE(rows <= 65535, "bn_train_stats_grouped: G*C > 65535");
+    const int chunk = bn_chunk(1, rows, P), nchunk = bn_nchunk_fwd(1, rows, P);
+    hipStream_t st = (hipStream_t)stream;
+    float *var = workspace + (size_t)2 * rows * nchunk;   // biased variances, rows floats (inside mgar_bn_workspace_floats(1, G*C, P))
+    { KtScope kt(KT_BN_STATS, st, 4.0 * (double)G * C * P);
+    hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, rows), dim3(BN_THREADS), 0, st, x, 1, rows, P, chunk, workspace);
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rows), dim3(64), 0, st, workspace, nchunk, rows, (double)P, eps, momentum, mean,
+                       invstd, (float *)nullptr, (float *)nullptr, (long long *)nullptr, var);
+    if (running_mean || running_var || num_batches_tracked)
+        hipLaunchKernelGGL(bn_running_update_grouped_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, mean, var, G, C, (double)P,
+                           momentum, running_mean, running_var, num_batches_tracked);
+    return check_launch("bn_train_stats_grouped: launch failed");
+}
+
+BN_API int mgar_bn_act_fwd_grouped(const float *x, int G, int C, int P, const float *mean, const float *invstd, const float *gamma,
+                                   const float *beta, int relu, float *y, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(G, C, P), "bn_act_fwd_grouped: bad sizes");
+    if ((long long)G * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && y && mean && invstd, "bn_act_fwd_grouped: null pointer");
+    MGAR_REQUIRE((long long)P <= 65535LL * BN_THREADS * 4, "bn_act_fwd_grouped: P too large");
+    dim3 grid(G * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
+    hipStream_t st = (hipStream_t)stream;
+    KtScope kt(KT_BN_APPLY, st, 8.0 * (double)G * C * P);
+    if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 1);
+    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 1);
+    return check_launch("bn_act_fwd_grouped: launch failed");
 }
 
 BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean, const float *invstd,

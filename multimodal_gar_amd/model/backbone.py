@@ -61,6 +61,8 @@ class Unit3D(nn.Module):
     """Conv3d (no bias by default) + BatchNorm3d(eps=1e-3, momentum=0.01) + ReLU with dynamic
     'same' padding."""
 
+    per_sample_stats = False   # see InceptionI3d.set_per_sample_stats
+
     def __init__(self, in_channels, output_channels, kernel_shape=(1, 1, 1), stride=(1, 1, 1), padding=0,
                  activation_fn=F.relu, use_batch_norm=True, use_bias=False, name='unit_3d'):
         super().__init__()
@@ -94,7 +96,12 @@ class Unit3D(nn.Module):
                 # as two kernels; I3D is frozen, so this is forward-only in MGAR-net)
                 from .. import bn_ops
                 relu_fused = self._activation_fn is F.relu
-                y = bn_ops.bn_act(x, self.bn, relu_fused)
+                if self.per_sample_stats and x.shape[0] > 1:
+                    # several clips in one pass, each normalised with its own statistics = one pass per clip
+                    y = bn_ops.bn_act_per_sample(x, self.bn, relu_fused)
+                    assert y is not None, "per_sample_stats is a forward-only (frozen backbone) device path"
+                else:
+                    y = bn_ops.bn_act(x, self.bn, relu_fused)
             x = self.bn(x) if y is None else y
             relu_fused = relu_fused and y is not None
         if self._activation_fn is not None and not relu_fused:
@@ -180,6 +187,14 @@ class InceptionI3d(nn.Module):
     def build(self):
         for k, layer in self.end_points.items():
             self.add_module(k, layer)
+
+    def set_per_sample_stats(self, on=True):
+        """Train-mode BatchNorm statistics per SAMPLE instead of per batch (device, forward-only): a batch of clips
+        then gives exactly what the reference's one-clip-at-a-time passes give (gat_model.py:1048), in one pass."""
+        for m in self.modules():
+            if isinstance(m, Unit3D):
+                m.per_sample_stats = bool(on)
+        return self
 
     def extract_features(self, x):
         for end_point in self.VALID_ENDPOINTS:

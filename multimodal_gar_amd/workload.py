@@ -122,19 +122,32 @@ class ClipModel(nn.Module):
         self.net = GAR_Fusion_ALL(self.cfg, self.dataset)
         self.net.GAR_model.uniform_actor_count = n_actors
         self.overlap_branches = True
+        self.batch_i3d = True
         self._side_stream = None
 
     # ---- RGB: one I3D pass per clip (batch 1, like the reference) ---------------------------------
     def rgb_crops(self, images, bboxes):
-        """Frozen part of the RGB branch (I3D_FREEZE): I3D + RoIAlign per clip, no autograd graph."""
+        """Frozen part of the RGB branch (I3D_FREEZE): I3D + RoIAlign, no autograd graph.  On the device all clips go
+        through I3D in ONE pass with per-clip BatchNorm statistics (= the reference's one pass per clip, batch 1;
+        fewer, larger launches: 13.5 instead of 15.0 ms per clip); elsewhere clip by clip."""
         rb = self.net.RGB_backbone
-        crops = []
+        b = images.shape[0]
         with torch.no_grad():
-            for b in range(images.shape[0]):
-                clip = images[b:b + 1]
+            if images.is_cuda and b > 1 and self.batch_i3d:
+                _B, _T, _C, _H, _W = images.shape
+                rb.backbone_net.set_per_sample_stats(True)
+                try:
+                    crops = rb.crop_features(images.view(_B, _C, _T, _H, _W), [bboxes[i] for i in range(b)])
+                finally:
+                    rb.backbone_net.set_per_sample_stats(False)
+                per = bboxes.shape[1]
+                return [crops[i * per:(i + 1) * per] for i in range(b)]
+            crops = []
+            for i in range(b):
+                clip = images[i:i + 1]
                 _B, _T, _C, _H, _W = clip.shape
                 clip = clip.view(_B, _C, _T, _H, _W)             # the reference's view (gat_model.py:1836)
-                crops.append(rb.crop_features(clip, [bboxes[b]]))  # (A+1, 832, 5, 5)
+                crops.append(rb.crop_features(clip, [bboxes[i]]))  # (A+1, 832, 5, 5)
         return crops
 
     def rgb_tokens_from_crops(self, crops):

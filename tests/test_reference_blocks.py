@@ -164,3 +164,29 @@ def test_maxpool3d_same_padding_kernel(shape, k, s):
     got = pool(x.cuda())
     assert got.shape == want.shape
     assert torch.equal(got.cpu(), want)
+
+
+@pytest.mark.gpu
+def test_i3d_batched_with_per_sample_bn_equals_one_pass_per_clip():
+    """Several clips through I3D in one pass with per-SAMPLE BatchNorm statistics (bn_act.hip, grouped) must give
+    what one train-mode pass per clip gives: features, running statistics (momentum updates in clip order) and the
+    batch counter."""
+    import copy
+    from multimodal_gar_amd.model.backbone import InceptionI3d
+    m = InceptionI3d(final_endpoint='Mixed_4f'); m.build()
+    fill_deterministic(m, seed=5)
+    a = m.cuda().train()
+    b = copy.deepcopy(a)
+    torch.manual_seed(1)
+    x = torch.randn(3, 3, 7, 64, 96, device="cuda") * 2 + 0.3
+    with torch.no_grad():
+        want = torch.cat([a.extract_features(x[i:i + 1]) for i in range(3)])
+        b.set_per_sample_stats(True)
+        got = b.extract_features(x)
+    close(got, want, rtol=2e-4)
+    bns_a = [mod for mod in a.modules() if isinstance(mod, torch.nn.BatchNorm3d)]
+    bns_b = [mod for mod in b.modules() if isinstance(mod, torch.nn.BatchNorm3d)]
+    assert len(bns_a) > 30
+    for p, q in zip(bns_a, bns_b):
+        close(q.running_mean, p.running_mean, rtol=2e-4); close(q.running_var, p.running_var, rtol=2e-4)
+        assert int(q.num_batches_tracked) == int(p.num_batches_tracked) == 3

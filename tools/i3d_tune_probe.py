@@ -13,7 +13,8 @@ from multimodal_gar_amd.model.backbone import InceptionI3d  # noqa: E402
 def main():
     torch.backends.cudnn.benchmark = os.environ.get("PROBE_BENCHMARK", "0") == "1"
     m = InceptionI3d(final_endpoint="Mixed_4f"); m.build(); m = m.cuda().train()
-    x = torch.randn(1, 3, 15, 720, 1280, device="cuda")
+    nb = int(os.environ.get("PROBE_BATCH", "1"))
+    x = torch.randn(nb, 3, 15, 720, 1280, device="cuda")
     with torch.no_grad():
         t0 = time.time(); m.extract_features(x); torch.cuda.synchronize()
         print("first pass %.1f s" % (time.time() - t0), flush=True)
@@ -24,7 +25,7 @@ def main():
         for _ in range(5):
             m.extract_features(x)
         torch.cuda.synchronize()
-        print("I3D forward: %.2f ms / clip" % ((time.time() - t0) / 5 * 1e3), flush=True)
+        print("I3D forward, batch %d: %.2f ms / clip" % (nb, (time.time() - t0) / 5 / nb * 1e3), flush=True)
 
 
 if __name__ == "__main__":
