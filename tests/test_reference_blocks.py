@@ -183,10 +183,10 @@ def test_i3d_batched_with_per_sample_bn_equals_one_pass_per_clip():
         want = torch.cat([a.extract_features(x[i:i + 1]) for i in range(3)])
         b.set_per_sample_stats(True)
         got = b.extract_features(x)
-    close(got, want, rtol=2e-4)
+    close(got, want.cpu().numpy(), rtol=2e-4)
     bns_a = [mod for mod in a.modules() if isinstance(mod, torch.nn.BatchNorm3d)]
     bns_b = [mod for mod in b.modules() if isinstance(mod, torch.nn.BatchNorm3d)]
     assert len(bns_a) > 30
     for p, q in zip(bns_a, bns_b):
-        close(q.running_mean, p.running_mean, rtol=2e-4); close(q.running_var, p.running_var, rtol=2e-4)
+        close(q.running_mean, p.running_mean.cpu().numpy(), rtol=2e-4); close(q.running_var, p.running_var.cpu().numpy(), rtol=2e-4)
         assert int(q.num_batches_tracked) == int(p.num_batches_tracked) == 3
