@@ -57,6 +57,16 @@ int mgar_ktimer_read(int id, double *total_ms, long long *launches, double *tota
 int mgar_ball_query_batch(int b, int n, int m, float radius, int nsample,
                           const float *new_xyz, const float *xyz, int *idx, void *stream);
 
+/* Multi-scale grouping: nr (2..4) (radius, nsample) pairs against the same centres and cloud in ONE
+ * scan (each squared distance is computed once); idx[r] receives exactly what the single-radius entry
+ * point writes for (radii[r], nsamples[r]).  radii / nsamples / idx are HOST arrays of nr entries (idx:
+ * device pointers).  Stack variant: rows of empty balls start with -1 as in mgar_ball_query_stack. */
+int mgar_ball_query_multi_batch(int b, int n, int m, int nr, const float *radii, const int *nsamples,
+                                const float *new_xyz, const float *xyz, int *const *idx, void *stream);
+int mgar_ball_query_multi_stack(int B, int M, int nr, const float *radii, const int *nsamples, const float *new_xyz,
+                                const int *new_xyz_batch_cnt, const float *xyz, const int *xyz_batch_cnt,
+                                int *const *idx, void *stream);
+
 /* group_points_wrapper / group_points_grad_wrapper   pointnet2_api.cpp:13-14
  * kernels              pointnet2_batch/src/group_points_gpu.cu:53-72, :14-31
  * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample);

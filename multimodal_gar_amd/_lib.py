@@ -28,6 +28,8 @@ _PROTOS = {
     "mgar_group_points_grad_batch": [_I, _I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_gather_points_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_gather_points_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_ball_query_multi_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_ball_query_multi_stack": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_fps_batch": [_I, _I, _I, _P, _P, _P, _P],
     "mgar_morton_codes": [_I, _I, _P, _P, _P],
     "mgar_fps_batch_perm": [_I, _I, _I, _P, _P, _P, _P, _P],
@@ -129,6 +131,15 @@ def call(name, *args):
     if rc != 0:
         raise MgarError("%s failed with code %d: %s" % (name, rc, _cdll.mgar_last_error().decode()))
     return rc
+
+
+def host_arrays(radii, nsamples, idx_tensors):
+    """ctypes host arrays (float[], int[], void*[]) for the multi-radius ball query entry points."""
+    n = len(radii)
+    fa = (ctypes.c_float * n)(*[float(r) for r in radii])
+    ia = (ctypes.c_int * n)(*[int(s) for s in nsamples])
+    pa = (ctypes.c_void_p * n)(*[iptr(t) for t in idx_tensors])
+    return fa, ia, pa
 
 
 def kernel_timers(enable=None, reset=True):

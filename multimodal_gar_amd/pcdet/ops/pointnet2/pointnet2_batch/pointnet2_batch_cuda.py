@@ -15,6 +15,15 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     return 1
 
 
+def ball_query_multi_wrapper(b, n, m, radii, nsamples, new_xyz, xyz, idx_list):
+    """Several (radius, nsample) pairs in one scan; idx_list[r] (b, m, nsamples[r]) as ball_query_wrapper fills it."""
+    if len(radii) == 1:
+        return ball_query_wrapper(b, n, m, radii[0], nsamples[0], new_xyz, xyz, idx_list[0])
+    fa, ia, pa = L.host_arrays(radii, nsamples, idx_list)
+    L.call("mgar_ball_query_multi_batch", b, n, m, len(radii), fa, ia, L.fptr(new_xyz), L.fptr(xyz), pa, L.stream_of(xyz))
+    return 1
+
+
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     L.call("mgar_group_points_batch", b, c, n, npoints, nsample, L.fptr(points), L.iptr(idx), L.fptr(out),
            L.stream_of(points))

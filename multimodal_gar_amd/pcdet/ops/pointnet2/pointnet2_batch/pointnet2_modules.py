@@ -48,12 +48,18 @@ class _PointnetSAModuleBase(nn.Module):
             xyz_t = xyz.transpose(1, 2).contiguous()
             new_xyz = pointnet2_utils.gather_operation(xyz_t, picked).transpose(1, 2).contiguous()
         per_scale = []
-        for grouper, mlp in zip(self.groupers, self.mlps):
-            if (self.pool_method == 'max_pool' and features is not None and xyz.is_cuda
+        fold = [k for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps))
+                if (self.pool_method == 'max_pool' and features is not None and xyz.is_cuda
                     and isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz
-                    and mlp.first_layer_foldable(3 + features.shape[1])):
+                    and mlp.first_layer_foldable(3 + features.shape[1]))]
+        # the scales share centres and cloud: all their ball queries in one scan
+        pre_idx = dict(zip(fold, pointnet2_utils.ball_query_multi([self.groupers[k].radius for k in fold],
+                                                                  [self.groupers[k].nsample for k in fold], xyz, new_xyz))) \
+            if len(fold) > 1 and hasattr(pointnet2_utils.pointnet2, "ball_query_multi_wrapper") else {}
+        for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
+            if k in fold:
                 # "project, then group": layer 0 is linear, apply its feature half to the N points first
-                y0 = grouper.forward_projected(xyz, new_xyz, features, mlp[0].weight)
+                y0 = grouper.forward_projected(xyz, new_xyz, features, mlp[0].weight, idx=pre_idx.get(k))
                 per_scale.append(mlp.forward_maxpool(y0, start=1))
                 continue
             grouped = grouper(xyz, new_xyz, features)          # (B, C', npoint, nsample)

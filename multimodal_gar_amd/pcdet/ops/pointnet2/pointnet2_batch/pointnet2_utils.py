@@ -197,6 +197,19 @@ class BallQuery(Function):
 ball_query = BallQuery.apply
 
 
+def ball_query_multi(radii, nsamples, xyz, new_xyz):
+    """ball_query for several (radius, nsample) pairs over the same xyz / new_xyz in one scan of the cloud
+    (csrc/ball_query.hip, ball_query_multi_kernel) -> list of idx tensors, each as BallQuery returns it."""
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()
+    batch, n_pts, _ = xyz.size()
+    npoint = new_xyz.size(1)
+    out = [_new(xyz, (batch, npoint, ns), torch.int32, 0) for ns in nsamples]
+    for g0 in range(0, len(out), 4):
+        pointnet2.ball_query_multi_wrapper(batch, n_pts, npoint, list(radii[g0:g0 + 4]), list(nsamples[g0:g0 + 4]), new_xyz, xyz,
+                                           out[g0:g0 + 4])
+    return out
+
+
 class _FusedQueryGroup(Function):
     """Relative xyz (3 rows) + grouped features (C rows) written once by one kernel
     (csrc/query_group.hip) instead of transpose / group / subtract / group / cat."""
@@ -273,14 +286,15 @@ class QueryAndGroup(nn.Module):
             return grouping_operation(features, idx)
         return _FusedQueryGroup.apply(xyz, new_xyz, features, idx)
 
-    def forward_projected(self, xyz, new_xyz, features, weight):
+    def forward_projected(self, xyz, new_xyz, features, weight, idx=None):
         """First shared-MLP layer folded into the grouping: returns  W [rel_xyz ; grouped features]
         (B, C_out, npoint, nsample) for a bias-free point-wise conv weight (C_out, 3 + C), without
         ever building the (3 + C)-channel grouped tensor."""
         assert self.use_xyz and features is not None
         w = weight.view(weight.shape[0], -1)
         zf = torch.bmm(w[:, 3:].unsqueeze(0).expand(features.shape[0], -1, -1), features)     # (B, C_out, N)
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         return _FusedQueryGroupProj.apply(xyz, new_xyz, zf, w[:, :3], idx)
 
 

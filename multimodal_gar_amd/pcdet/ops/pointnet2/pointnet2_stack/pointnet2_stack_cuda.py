@@ -13,6 +13,16 @@ def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, x
     return 1
 
 
+def ball_query_multi_wrapper(B, M, radii, nsamples, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_list):
+    """Several (radius, nsample) pairs in one scan; idx_list[r] (M, nsamples[r]) as ball_query_wrapper fills it."""
+    if len(radii) == 1:
+        return ball_query_wrapper(B, M, radii[0], nsamples[0], new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_list[0])
+    fa, ia, pa = L.host_arrays(radii, nsamples, idx_list)
+    L.call("mgar_ball_query_multi_stack", B, M, len(radii), fa, ia, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt), L.fptr(xyz),
+           L.iptr(xyz_batch_cnt), pa, L.stream_of(xyz))
+    return 1
+
+
 def voxel_query_wrapper(M, R1, R2, R3, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
                         point_indices, idx):
     L.call("mgar_voxel_query_stack", M, R1, R2, R3, nsample, float(radius), z_range, y_range, x_range,

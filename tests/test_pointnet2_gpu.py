@@ -67,6 +67,40 @@ def test_ball_query_stack_ragged(ops, oracle):
     assert want_empty.any() and (~want_empty).any()
 
 
+@pytest.mark.parametrize("radii,nsamples", [((0.1, 0.5), (16, 32)), ((0.4, 0.8, 1.6), (16, 16, 16)), ((2.0, 0.3, 0.9, 5.0), (3, 64, 1, 8))])
+def test_ball_query_multi_radius_equals_single_radius(ops, radii, nsamples):
+    """All radii of a multi-scale module in ONE scan (ball_query_multi_kernel): every idx tensor must be exactly
+    what the single-radius kernel writes -- batch layout (untouched rows for empty balls) and stack layout
+    (-1 marker, ragged segments, a far-away query)."""
+    from multimodal_gar_amd import _lib as L
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as CB
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as CS
+    xyz = dev(scene_xyz(5, 3, 3000))
+    new_xyz = torch.cat([xyz[:, :700] + 0.01, torch.full((3, 1, 3), 400.0, device="cuda")], 1).contiguous()   # last query: empty ball
+    b, n, m = 3, 3000, 701
+    single = [torch.full((b, m, ns), -7, dtype=torch.int32, device="cuda") for ns in nsamples]
+    multi = [t.clone() for t in single]
+    for r, ns, t in zip(radii, nsamples, single):
+        CB.ball_query_wrapper(b, n, m, r, ns, new_xyz, xyz, t)
+    CB.ball_query_multi_wrapper(b, n, m, list(radii), list(nsamples), new_xyz, xyz, multi)
+    for a, c in zip(single, multi):
+        assert torch.equal(a, c)
+    assert all((t[:, -1] == -7).all() for t in multi)            # empty ball: the caller's row is left alone
+    # stack layout, ragged
+    sx = xyz.reshape(-1, 3).contiguous()[:8000]
+    cnt = torch.tensor([3000, 3000, 2000], dtype=torch.int32, device="cuda")
+    q = torch.cat([sx[:300] + 0.02, sx[3000:3100], torch.full((1, 3), -300.0, device="cuda"), sx[6000:6450] - 0.01]).contiguous()
+    qcnt = torch.tensor([300, 101, 450], dtype=torch.int32, device="cuda")
+    single = [torch.zeros((q.shape[0], ns), dtype=torch.int32, device="cuda") for ns in nsamples]
+    multi = [t.clone() for t in single]
+    for r, ns, t in zip(radii, nsamples, single):
+        CS.ball_query_wrapper(3, q.shape[0], r, ns, q, qcnt, sx, cnt, t)
+    CS.ball_query_multi_wrapper(3, q.shape[0], list(radii), list(nsamples), q, qcnt, sx, cnt, multi)
+    for a, c in zip(single, multi):
+        assert torch.equal(a, c)
+    assert all(int(t[400, 0]) == -1 for t in multi)
+
+
 # --------------------------------------------------------------------- FPS
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (40, 40), (64, 10), (100, 37), (256, 256), (300, 64), (1000, 100),
                                  (1024, 128), (1500, 200), (4096, 512), (5000, 300), (16384, 256)])
