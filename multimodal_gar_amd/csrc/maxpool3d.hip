@@ -9,11 +9,10 @@
 // ~10 ms per c3 step.  I3D is frozen in MGAR-net (I3D_FREEZE), so only the forward is needed.
 // The window is read straight from the un-padded input (rows stay in L1/L2), and "the window
 // touches the zero padding" is folded in as max(., 0).  HBM-bound: input read once, output written
-// once.  Main kernel: one thread per FOUR consecutive outputs of a row; per input row of the window
-// it loads one aligned 16-byte vector (two for stride 2) plus the one or two edge elements and
-// forms the four horizontal maxima in registers -- 3 loads per row and 4 outputs instead of 12 --
-// and writes a float4; (t, nc) come from the grid, so there is no 64-bit index arithmetic.  A
-// one-thread-per-output kernel covers the other geometries.
+// once.  Main kernel: one thread per FOUR consecutive outputs of a row, walking the input slices t once
+// with the last three 2-D pooled quads in registers (see maxpool3d_same_vec_kernel); per input row it
+// loads one aligned 16-byte vector (two for stride 2) plus the one or two edge elements and forms the four
+// horizontal maxima in registers.  A one-thread-per-output kernel covers the other geometries.
 #include "common.hpp"
 
 namespace mgar {
@@ -45,24 +44,31 @@ __global__ __launch_bounds__(256) void maxpool3d_same_kernel(const float *__rest
     }
 }
 
-// kw == 3 and (SW == 1, front pad 1) or (SW == 2, front pad 0); W % 4 == 0, Wo % 4 == 0.
-// grid (ceil(Ho * Wo/4 / 256), To, NC)
+// kw == 3 and (SW == 1, front pad 1) or (SW == 2, front pad 0); W % 4 == 0, Wo % 4 == 0; kt <= 3.
+// One thread owns a quad of output columns (ho, 4 wo) of one (n, c) and walks the input slices t once: per slice
+// it forms the 2-D pooled quad (kh rows x [one aligned 16-byte load (two for stride 2) + the edge elements]) and
+// keeps the last three of them in registers; an output slice is emitted when its last input slice has been seen.
+// Every input element is loaded once per (kh x kw) window it belongs to -- 9 loads per output quad instead of 27
+// for the 3x3x3 pools, and the t-reuse no longer depends on the L2.  grid (ceil(Ho * Wo/4 / 256), NC)
 template <int SW>
 __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__restrict__ x, Pool3dGeom g, float *__restrict__ y) {
     const int nq = g.Wo >> 2;
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int ho = q / nq, wq = q - ho * nq;
     if (ho >= g.Ho) return;
-    const int to = blockIdx.y;
-    const size_t nc = blockIdx.z;
-    const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph;
-    const int t1 = t0 + g.kt, h1 = h0 + g.kh;
-    const bool pad_th = t0 < 0 || h0 < 0 || t1 > g.T || h1 > g.H;
+    const size_t nc = blockIdx.y;
+    const int h0 = ho * g.sh - g.ph, h1 = h0 + g.kh;
+    const bool pad_h = h0 < 0 || h1 > g.H;
     const float ninf = -__builtin_inff();
-    float b0 = ninf, b1 = ninf, b2 = ninf, b3 = ninf;
     const float *base = x + nc * g.T * g.H * g.W;
     const int wb = wq * 4 * SW;  // first aligned input column of this quad
-    for (int t = max(t0, 0); t < min(t1, g.T); ++t)
+    const bool pad_l = SW == 1 && wb == 0;
+    const bool pad_r = SW == 1 ? (wb + 4 >= g.W) : (wb + 8 >= g.W);
+    float4 p0 = make_float4(ninf, ninf, ninf, ninf), p1 = p0, p2 = p0;   // 2-D pooled quads of slices t-2, t-1, t
+    int to = 0;
+    for (int t = 0; t < g.T; ++t) {
+        p0 = p1; p1 = p2;
+        float b0 = ninf, b1 = ninf, b2 = ninf, b3 = ninf;
         for (int h = max(h0, 0); h < min(h1, g.H); ++h) {
             const float *row = base + ((size_t)t * g.H + h) * g.W + wb;
             if (SW == 1) {  // outputs j = 0..3 cover inputs wb + j - 1 .. wb + j + 1
@@ -83,13 +89,23 @@ __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__
                 b3 = fmaxf(b3, fmaxf(fmaxf(u.z, u.w), rgt));
             }
         }
-    // zero padding takes part in the max wherever the window leaves the input
-    const bool pad_l = SW == 1 && wb == 0;
-    const bool pad_r = SW == 1 ? (wb + 4 >= g.W) : (wb + 8 >= g.W);
-    if (pad_th || pad_l) b0 = fmaxf(b0, 0.f);
-    if (pad_th) { b1 = fmaxf(b1, 0.f); b2 = fmaxf(b2, 0.f); }
-    if (pad_th || pad_r) b3 = fmaxf(b3, 0.f);
-    *reinterpret_cast<float4 *>(y + ((nc * g.To + to) * g.Ho + ho) * g.Wo + wq * 4) = make_float4(b0, b1, b2, b3);
+        p2 = make_float4(b0, b1, b2, b3);
+        // emit every output slice whose window ends at (or is clipped to) input slice t
+        while (to < g.To) {
+            const int t0 = to * g.st - g.pt, t1 = t0 + g.kt;
+            if (min(t1, g.T) - 1 != t) break;
+            const int lo = max(t0, 0);                     // window = slices lo .. t  (at most 3)
+            float4 r = p2;
+            if (lo <= t - 1) { r.x = fmaxf(r.x, p1.x); r.y = fmaxf(r.y, p1.y); r.z = fmaxf(r.z, p1.z); r.w = fmaxf(r.w, p1.w); }
+            if (lo <= t - 2) { r.x = fmaxf(r.x, p0.x); r.y = fmaxf(r.y, p0.y); r.z = fmaxf(r.z, p0.z); r.w = fmaxf(r.w, p0.w); }
+            const bool pad = pad_h || t0 < 0 || t1 > g.T;  // zero padding takes part in the max wherever the window leaves the input
+            if (pad || pad_l) r.x = fmaxf(r.x, 0.f);
+            if (pad) { r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); }
+            if (pad || pad_r) r.w = fmaxf(r.w, 0.f);
+            *reinterpret_cast<float4 *>(y + ((nc * g.To + to) * g.Ho + ho) * g.Wo + wq * 4) = r;
+            ++to;
+        }
+    }
 }
 
 }  // namespace mgar
@@ -111,8 +127,8 @@ extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd(co
                  front(T, kt, st), front(H, kh, sh), front(W, kw, sw)};
     KtScope ktimer(KT_MAXPOOL3D, (hipStream_t)stream, 4.0 * NC * ((double)T * H * W + (double)g.To * g.Ho * g.Wo));
     const bool vec1 = kw == 3 && sw == 1 && g.pw == 1, vec2 = kw == 3 && sw == 2 && g.pw == 0 && W % 2 == 0;
-    if ((vec1 || vec2) && W % 4 == 0 && g.Wo % 4 == 0 && g.To <= 65535 && NC <= 65535 && (!vec2 || W >= 8)) {
-        dim3 grid(ceil_div(g.Ho * (g.Wo / 4), 256), g.To, NC);
+    if ((vec1 || vec2) && kt <= 3 && W % 4 == 0 && g.Wo % 4 == 0 && NC <= 65535 && (!vec2 || W >= 8)) {
+        dim3 grid(ceil_div(g.Ho * (g.Wo / 4), 256), NC);
         if (vec1) hipLaunchKernelGGL(maxpool3d_same_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
         else hipLaunchKernelGGL(maxpool3d_same_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
         return check_launch("maxpool3d_same_fwd: launch failed");
