@@ -159,6 +159,8 @@ __device__ __forceinline__ void dpp_max_step(float &v, int &i) {
     max_pair(v, i, ov, oi);
 }
 
+constexpr int BN_MAX_V = 4;   // float4 per thread: four independent 16-byte loads in flight
+
 template <bool RELU, int G>   // G = NS / 4 lanes per group: 1, 2, 4, 8 or 16
 __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__restrict__ x, int C, int M, int NS,
                                                                 const float *__restrict__ mean, const float *__restrict__ invstd,
@@ -169,30 +171,40 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__r
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
     const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
-    const long long q = (long long)blockIdx.y * BN_THREADS + threadIdx.x;   // float4 index inside the row
     const long long nq = (long long)M * G;
-    const bool live = q < nq;                                                // whole groups are live or dead together
-    float best = -__builtin_inff();
-    int bi = 0;
-    if (live) {
-        const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)row * M * NS + q * 4);
-        const int s0 = (int)(q % G) * 4;
-        const float a[4] = {v.x * sc + sh, v.y * sc + sh, v.z * sc + sh, v.w * sc + sh};
+    const float *xr = x + (size_t)row * M * NS;
+    float4 v[BN_MAX_V];
+    long long qs[BN_MAX_V];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (a[u] > best) { best = a[u]; bi = s0 + u; }
+    for (int u = 0; u < BN_MAX_V; ++u) {   // float4 index inside the row; whole groups are live or dead together
+        qs[u] = ((long long)blockIdx.y * BN_MAX_V + u) * BN_THREADS + threadIdx.x;
+        v[u] = qs[u] < nq ? *reinterpret_cast<const float4 *>(xr + qs[u] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (G >= 2) dpp_max_step<0xB1>(best, bi);    // quad_perm [1,0,3,2]  (xor 1)
-    if (G >= 4) dpp_max_step<0x4E>(best, bi);    // quad_perm [2,3,0,1]  (xor 2)
-    if (G >= 8) dpp_max_step<0x141>(best, bi);   // row_half_mirror      (acts as xor 4 once quads agree)
-    if (G >= 16) dpp_max_step<0x140>(best, bi);  // row_mirror           (acts as xor 8)
-    if (live && (threadIdx.x & (G - 1)) == 0) {
-        const long long m = q / G;
-        out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
-        arg[(size_t)row * M + m] = (unsigned char)bi;
-        // the pre-BN value at the arg-max (the line was just read: an L1/L2 hit), so that the backward
-        // reduction reads three coalesced (B,C,M) arrays instead of gathering one element per group
-        if (xarg) xarg[(size_t)row * M + m] = x[(size_t)row * M * NS + m * NS + bi];
+#pragma unroll
+    for (int u = 0; u < BN_MAX_V; ++u) {
+        const long long q = qs[u];
+        const bool live = q < nq;
+        float best = -__builtin_inff();
+        int bi = 0;
+        if (live) {
+            const int s0 = (int)(q % G) * 4;
+            const float a[4] = {v[u].x * sc + sh, v[u].y * sc + sh, v[u].z * sc + sh, v[u].w * sc + sh};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+                if (a[w] > best) { best = a[w]; bi = s0 + w; }
+        }
+        if (G >= 2) dpp_max_step<0xB1>(best, bi);    // quad_perm [1,0,3,2]  (xor 1)
+        if (G >= 4) dpp_max_step<0x4E>(best, bi);    // quad_perm [2,3,0,1]  (xor 2)
+        if (G >= 8) dpp_max_step<0x141>(best, bi);   // row_half_mirror      (acts as xor 4 once quads agree)
+        if (G >= 16) dpp_max_step<0x140>(best, bi);  // row_mirror           (acts as xor 8)
+        if (live && (threadIdx.x & (G - 1)) == 0) {
+            const long long m = q / G;
+            out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
+            arg[(size_t)row * M + m] = (unsigned char)bi;
+            // the pre-BN value at the arg-max (the line was just read: an L1/L2 hit), so that the backward
+            // reduction reads three coalesced (B,C,M) arrays instead of gathering one element per group
+            if (xarg) xarg[(size_t)row * M + m] = xr[m * NS + bi];
+        }
     }
 }
 
@@ -517,7 +529,7 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
     KtScope kt(KT_BN_MAX, st, (double)B * C * M * (4.0 * nsample + 5.0));
 #define BN_MAX_VEC(G)                                                                                                  \
     {                                                                                                                  \
-        dim3 gv(B * C, ceil_div((long long)M * (G), BN_THREADS));                                                      \
+        dim3 gv(B * C, ceil_div((long long)M * (G), BN_THREADS * BN_MAX_V));                                                      \
         if (relu) hipLaunchKernelGGL((bn_max_vec_kernel<true, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg); \
         else hipLaunchKernelGGL((bn_max_vec_kernel<false, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);     \
     }
