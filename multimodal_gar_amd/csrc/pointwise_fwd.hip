@@ -29,8 +29,10 @@ namespace mgar {
 
 typedef float __attribute__((ext_vector_type(16))) f32x16;
 
-constexpr int PF_KC = 16;     // channels per slab (8 MFMA k-steps)
 constexpr int PF_COLS = 128;  // columns per wave tile
+// channels per slab (2 per MFMA k-step): 16, or 8 for the 64-output-channel instance so that its 128 accumulator
+// registers + two slab buffers stay under 256 VGPRs (2 waves per SIMD instead of 1)
+template <int OB> struct PfSlab { static constexpr int KC = OB == 1 ? 16 : 8; };
 
 struct PfArgs {
     const float *x;
@@ -43,7 +45,8 @@ struct PfArgs {
 };
 
 template <int OB>
-__global__ __launch_bounds__(256) void pointwise_fwd_kernel(PfArgs a) {
+__global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
+    constexpr int PF_KC = PfSlab<OB>::KC, KS = PF_KC / 2;
     constexpr int WLD = OB == 1 ? 32 : 96;  // LDS row stride of W: the two half-waves hit disjoint banks
     extern __shared__ float lds[];          // [nkc*16][WLD] weights, then [nkc*16][2] (sc, sh)
     const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
@@ -83,23 +86,23 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PfArgs a) {
             for (int r = 0; r < 16; ++r) acc[ob][j][r] = 0.f;
 
     // slab loads of step s (tile s / nkc of this wave, channel slab s % nkc)
-    auto issue = [&](long long s, float4 (&buf)[8]) {
+    auto issue = [&](long long s, float4 (&buf)[KS]) {
         const long long t = wave_id + (s / nkc) * nwaves;
         const int kc = (int)(s % nkc);
         const int b = (int)(t / tiles_per_b);
         const int p = (int)(t - (long long)b * tiles_per_b) * PF_COLS + 4 * l;
         const float *src = a.x + ((size_t)b * a.Cin + kc * PF_KC + h) * a.P + p;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int ch = kc * PF_KC + 2 * ks + h;
             buf[ks] = (ch < a.Cin && p < a.P) ? *reinterpret_cast<const float4 *>(src + (size_t)2 * ks * a.P)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto compute = [&](long long s, float4 (&buf)[8]) {
+    auto compute = [&](long long s, float4 (&buf)[KS]) {
         const int kc = (int)(s % nkc);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             const int ch = kc * PF_KC + 2 * ks + h;
             float4 v = buf[ks];
             if (has_act) {
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PfArgs a) {
         }
     };
 
-    float4 buf0[8], buf1[8];
+    float4 buf0[KS], buf1[KS];
     issue(0, buf0);
     for (long long s = 0; s < steps; s += 2) {
         if (s + 1 < steps) issue(s + 1, buf1);
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256) void pointwise_fwd_kernel(PfArgs a) {
 
 template <int OB>
 static void launch_pf(const PfArgs &a, hipStream_t st) {
-    constexpr int WLD = OB == 1 ? 32 : 96;
+    constexpr int WLD = OB == 1 ? 32 : 96, PF_KC = PfSlab<OB>::KC;
     const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
     const int lds = nkc * PF_KC * (WLD + 2) * (int)sizeof(float);
     static int attr_lds = 0;
