@@ -215,88 +215,6 @@ __global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, 
     }
 }
 
-// Backward of the stack grouping with in-LDS combining.  The float-atomic scatter above runs at the chip's
-// atomic rate (~1.3 TB/s of added bytes): 1.7 ms per scale of the RoI-grid pooling at config c3.  Neighbouring
-// grid points of an actor box share most of their neighbours, so a workgroup takes a LARGE tile of columns
-// (QH_COLS = 2048 = 128 queries x 16 samples), maps the distinct source rows of the tile to slots of an LDS hash
-// table (open addressing, atomicCAS), accumulates the tile's gradient columns into the slots with LDS float
-// atomics (row stride 33: lanes of a wave hit different banks), and flushes each occupied slot once with
-// contiguous 128-byte global atomics -- ~10x fewer global atomics.  Columns whose row finds no slot (table
-// full after QH_PROBES probes) go straight to global memory, so the result never depends on the table size.
-constexpr int QH_COLS = 2048;
-constexpr int QH_SLOTS = 1024;
-constexpr int QH_PROBES = 16;
-constexpr int QH_LD = QS_CH + 1;
-
-__global__ __launch_bounds__(256) void qg_stack_bwd_hash_kernel(int B, int M, int C, int nsample, const float *__restrict__ grad_y,
-                                                                const int *__restrict__ idx, const int *__restrict__ q_cnt,
-                                                                const int *__restrict__ p_cnt, float *__restrict__ grad_features,
-                                                                int ld) {
-    extern __shared__ int qh_lds[];
-    int *keys = qh_lds;                                  // [QH_SLOTS] source row of the slot, -1 = free
-    int *slot_of = qh_lds + QH_SLOTS;                    // [QH_COLS]  slot of each column, -1 = no slot, -2 = empty ball
-    int *src_of = slot_of + QH_COLS;                     // [QH_COLS]  source row of each column
-    float *acc = reinterpret_cast<float *>(src_of + QH_COLS);   // [QH_SLOTS][QH_LD]
-    __shared__ int seg_q_end, seg_p_start;
-    const long long total = (long long)M * nsample;
-    const long long col0 = (long long)blockIdx.x * QH_COLS;
-    const int ncol = (int)min((long long)QH_COLS, total - col0);
-    const size_t ms = (size_t)total;
-    for (int i = threadIdx.x; i < QH_SLOTS; i += 256) keys[i] = -1;
-    for (int i = threadIdx.x; i < QH_SLOTS * QH_LD; i += 256) acc[i] = 0.f;
-    if (threadIdx.x == 0) {
-        const Segment sg = find_segment((int)(col0 / nsample), B, q_cnt, p_cnt);
-        seg_q_end = sg.a_start + q_cnt[sg.bs];
-        seg_p_start = sg.b_start;
-    }
-    __syncthreads();
-    // source row of every column, and its slot
-    for (int cl = threadIdx.x; cl < ncol; cl += 256) {
-        const long long col = col0 + cl;
-        const int m = (int)(col / nsample);
-        const int first = idx[(size_t)m * nsample];
-        int slot = -2, src = -1;
-        if (first >= 0) {
-            const int p_start = m < seg_q_end ? seg_p_start : find_segment(m, B, q_cnt, p_cnt).b_start;
-            src = p_start + idx[col];
-            unsigned h = ((unsigned)src * 2654435761u) >> 22;   // 10 bits
-            slot = -1;
-            for (int probe = 0; probe < QH_PROBES; ++probe) {
-                const int old = atomicCAS(&keys[h], -1, src);
-                if (old == -1 || old == src) { slot = (int)h; break; }
-                h = (h + 1) & (QH_SLOTS - 1);
-            }
-        }
-        slot_of[cl] = slot;
-        src_of[cl] = src;
-    }
-    __syncthreads();
-    for (int c0 = 0; c0 < C; c0 += QS_CH) {
-        const int nch = min(QS_CH, C - c0);
-        // accumulate: lanes along the columns (coalesced reads of the gradient rows)
-        for (int e = threadIdx.x; e < nch * QH_COLS; e += 256) {
-            const int ci = e / QH_COLS, cl = e - ci * QH_COLS;
-            if (cl >= ncol) continue;
-            const int slot = slot_of[cl];
-            if (slot == -2) continue;
-            const float v = grad_y[(size_t)(c0 + ci) * ms + col0 + cl];
-            if (slot >= 0) atomicAdd(&acc[slot * QH_LD + ci], v);
-            else atomicAdd(grad_features + (size_t)src_of[cl] * ld + c0 + ci, v);
-        }
-        __syncthreads();
-        // flush: lanes along c -- one contiguous 128-byte atomic piece per occupied slot
-        for (int e = threadIdx.x; e < QH_SLOTS * QS_CH; e += 256) {
-            const int slot = e / QS_CH, ci = e - slot * QS_CH;
-            const int key = keys[slot];
-            if (key >= 0 && ci < nch) {
-                atomicAdd(grad_features + (size_t)key * ld + c0 + ci, acc[slot * QH_LD + ci]);
-                acc[slot * QH_LD + ci] = 0.f;
-            }
-        }
-        __syncthreads();
-    }
-}
-
 constexpr int QG_LDS_MAX_FLOATS = 36864;
 
 }  // namespace mgar
@@ -394,19 +312,8 @@ static int qg_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, c
     if (B == 0 || total == 0 || C == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_y && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group (stack) bwd: null pointer");
     KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)total * (4.0 + 8.0 * C));
-    if (total >= 64 * QH_COLS) {   // enough tiles to fill the chip: combine duplicates in LDS first
-        static bool attr_set = false;
-        const int lds = (QH_SLOTS + 2 * QH_COLS) * (int)sizeof(int) + QH_SLOTS * QH_LD * (int)sizeof(float);
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)qg_stack_bwd_hash_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(qg_stack_bwd_hash_kernel, dim3(ceil_div(total, QH_COLS)), dim3(256), lds, (hipStream_t)stream, B, M, C,
-                           nsample, grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features, ld);
-    } else {
-        hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
-                           grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features, ld);
-    }
+    hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
+                       grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features, ld);
     return check_launch(what);
 }
 

@@ -432,39 +432,3 @@ def test_fused_query_group_stack_equals_op_chain(ops):
     cm, raw = qg.forward_channel_major(xyz, c, new_xyz, q, feats)
     assert cm.shape == (48, int(qcnt.sum()) * 16) and cm.is_contiguous()
     assert torch.equal(cm.view(48, -1, 16).permute(1, 0, 2), want)
-
-
-@pytest.mark.parametrize("spread", ["clustered", "uniform"])
-@pytest.mark.parametrize("chans", [32, 40])
-def test_query_group_stack_bwd_hash_combining(spread, chans):
-    """Large stack-layout scatter (qg_stack_bwd_hash_kernel: duplicates combined in an LDS hash table before the global
-    atomics).  'clustered' neighbourhoods fit the table; 'uniform' ones overflow it and take the direct path."""
-    from multimodal_gar_amd import _lib as L
-    rng = np.random.default_rng(3)
-    p_cnt = np.array([5000, 7000], np.int32); q_cnt = np.array([4000, 5000], np.int32)
-    ns, M, ld = 16, int(q_cnt.sum()), chans + 8
-    idx = np.zeros((M, ns), np.int32)
-    off = 0
-    for b in range(2):
-        for m in range(off, off + q_cnt[b]):
-            if spread == "clustered":
-                centre = (m * 7) % (p_cnt[b] - 40)
-                idx[m] = centre + rng.integers(0, 40, ns)
-            else:
-                idx[m] = rng.integers(0, p_cnt[b], ns)
-        off += q_cnt[b]
-    empty = rng.random(M) < 0.05
-    idx[empty, 0] = -1
-    gy = rng.standard_normal((chans, M * ns)).astype(np.float32)
-    want = np.zeros((int(p_cnt.sum()), ld), np.float64)
-    starts = np.concatenate([[0], np.cumsum(p_cnt)[:-1]])
-    seg = np.repeat(np.arange(2), q_cnt)
-    rows = (starts[seg][:, None] + idx).reshape(-1)
-    live = np.repeat(~empty, ns)
-    np.add.at(want, (rows[live][:, None], np.arange(chans)[None, :]), gy.T.astype(np.float64)[live])
-    got = torch.zeros((int(p_cnt.sum()), ld), device="cuda")
-    L.call("mgar_query_group_proj_stack_bwd", 2, M, chans, ns, L.fptr(dev(gy)), L.iptr(dev(idx)), L.iptr(dev(q_cnt)),
-           L.iptr(dev(p_cnt)), L.fptr(got), ld, L.stream_of(got))
-    g = got.cpu().numpy().astype(np.float64)
-    assert np.all(g[:, chans:] == 0)
-    np.testing.assert_allclose(g[:, :chans], want[:, :chans], rtol=1e-5, atol=2e-4)
