@@ -338,6 +338,7 @@ class TrainStep:
             loss = synthetic_loss(out)
             loss.backward()
         self.graph, self._loss = graph, loss.detach()
+        self._graph_grads = [p.grad for p in self.params]   # the buffers every replay writes (graph-private pool)
         return self
 
     def run(self, batch):
@@ -348,6 +349,8 @@ class TrainStep:
                 if torch.is_tensor(v):
                     self._static_batch[k].copy_(v)
         self.graph.replay()
+        for p, g in zip(self.params, self._graph_grads):      # an eager step in between re-points .grad elsewhere
+            p.grad = g
         self._exchange_gradients()
         self.opt.step()
         return self._loss

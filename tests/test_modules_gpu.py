@@ -296,7 +296,9 @@ def test_train_step_hip_graph_matches_eager():
     # float atomics reorder sums between runs and this tiny configuration amplifies that through its BatchNorms:
     # the graph must be no further from an eager run than a few times what two eager runs are from each other
     assert diff <= max(10 * noise, 1e-4), (diff, noise)
+    graph.run_eager(batch)                                 # an eager step in between must not detach .grad from the graph
     before = [p.detach().clone() for p in graph.params[:5]]
     losses = [float(graph.run(batch)) for _ in range(3)]
+    assert all(p.grad is g for p, g in zip(graph.params, graph._graph_grads))
     assert all(l == l and l < 1e6 for l in losses)
     assert any(not torch.equal(a, b) for a, b in zip(before, graph.params[:5]))
