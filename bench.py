@@ -192,12 +192,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
+    # MGAR_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a one-GPU box; RCCL
+    # refuses two ranks on one device); the real runs use nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("MGAR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     ddp = world > 1
     if ddp:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     assert args.clips % world == 0, "global clip batch must divide over the ranks"
     clips_local = args.clips // world
 
