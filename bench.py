@@ -74,7 +74,7 @@ MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kern
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # rocprofv3 --pmc passes, see profiles/README.md
 
 
-def kernel_rooflines(step, batch, frames, n_points):
+def kernel_rooflines(step, batch, frames, n_points, clips_local=None):
     """-> list of per-kernel roofline dicts for one training step, the dominant (largest total time) first."""
     from multimodal_gar_amd import _lib as L
     # one stream for this step: with the RGB branch on its side stream two kernels share the chip and the time
@@ -90,7 +90,9 @@ def kernel_rooflines(step, batch, frames, n_points):
     traffic = {}
     if os.path.exists(PMC_TRAFFIC_FILE):
         try:
-            traffic = json.load(open(PMC_TRAFFIC_FILE)).get("per_launch_bytes", {})
+            pmc = json.load(open(PMC_TRAFFIC_FILE))
+            # measured per launch at one per-rank batch size: only valid for that one
+            traffic = pmc.get("per_launch_bytes", {}) if pmc.get("clips_per_gpu") == clips_local else {}
         except (OSError, ValueError):
             traffic = {}
     res = []
@@ -259,7 +261,7 @@ def main():
     roof, kernels, cpu = None, None, None
     if not args.no_kernel_timing:
         if rank == 0:
-            kernels = kernel_rooflines(step, batch, clips_local * args.frames, args.points)
+            kernels = kernel_rooflines(step, batch, clips_local * args.frames, args.points, clips_local)
             roof = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step",
                                                "ms_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch")}
             log("dominant hand-written kernel: %s, %.2f ms/step in %d launches, %.0f %s (%.1f %% of peak)"

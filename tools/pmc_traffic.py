@@ -3,7 +3,7 @@
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d out_fetch -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d out_write -o p --output-format csv -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing
-    python tools/pmc_traffic.py out_fetch/p_counter_collection.csv out_write/p_counter_collection.csv > profiles/pmc_hbm_traffic.json
+    python tools/pmc_traffic.py out_fetch/p_counter_collection.csv out_write/p_counter_collection.csv [clips_per_gpu=8] > profiles/pmc_hbm_traffic.json
 
 Counters are in KiB (/opt/skills/guides/cdna_hip_programming.md: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024) and are
 collected in SEPARATE passes (FETCH_SIZE takes 3 of the 4 TCC slots, WRITE_SIZE 2).  gfx950 correction
@@ -51,6 +51,7 @@ def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"unit": "bytes per launch (HBM-side, FETCH_SIZE [x2 for float4 streaming readers] + WRITE_SIZE, KiB * 1024)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 at config c3",
+           "clips_per_gpu": int(sys.argv[3]) if len(sys.argv) > 3 else 8,   # bench.py attaches the figures only to this per-rank batch
            "per_launch_bytes": {}, "detail": {}}
     for k in KERNELS:
         if k not in fetch or k not in write:
