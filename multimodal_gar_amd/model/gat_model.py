@@ -681,15 +681,52 @@ class GAR_Fusion_Net3(nn.Module):
         res_feature = torch.cat([Rf, Lf], dim=-1)
         outs = []
         for prefix, feat in (("", res_feature), ("SG_", sg_features)):
-            for (name, k, _) in _HEAD_SPECS:
-                o = torch.zeros([S, MNP, k], device=device, dtype=feat.dtype)
-                o[:, :n] = getattr(self, prefix + name)(feat).view(S, n, k)
-                outs.append(o)
+            outs += self._heads_stacked(prefix, feat, S, n, MNP)
         card_feature = torch.cat((fused.max(dim=1)[0], A_theta.sum(dim=(1, 2)).view(S, 1)), dim=1)
         card_list = self.card_net(card_feature)
         A_list = torch.zeros([S, MNP, MNP], device=device, dtype=A_theta.dtype)
         A_list[:, :n, :n] = A_theta
         return (A_list, *outs, card_list)
+
+    def _heads_stacked(self, prefix, feat, S, n, MNP):
+        """The seven heads that share `feat` (Linear -> ReLU -> Dropout -> Linear -> softmax | sigmoid each,
+        reference :1160-1173) evaluated together: one GEMM over the stacked first layers, one dropout mask, one
+        block-diagonal GEMM for the second layers, one softmax over the three pose heads and one sigmoid over the
+        rest -- ~20 launches instead of ~110 (and as many again in the backward), which is what a rank that holds
+        a single clip is made of.  Returns the reference's per-head (S, MNP, k) tensors (views of one buffer)."""
+        heads = [getattr(self, prefix + name) for name, _, _ in _HEAD_SPECS]
+        if any(len(h) != 5 for h in heads):      # a head with BatchNorm: not stackable
+            outs = []
+            for h, (_, k, _) in zip(heads, _HEAD_SPECS):
+                o = torch.zeros([S, MNP, k], device=feat.device, dtype=feat.dtype)
+                o[:, :n] = h(feat).view(S, n, k)
+                outs.append(o)
+            return outs
+        ks = [k for _, k, _ in _HEAD_SPECS]
+        hid_dim = heads[0][0].out_features
+        w1 = torch.cat([h[0].weight for h in heads], 0)
+        b1 = torch.cat([h[0].bias for h in heads], 0)
+        hid = F.dropout(F.relu(F.linear(feat, w1, b1)), heads[0][2].p, self.training)            # (S*n, 7*hid)
+        w2 = feat.new_zeros(sum(ks), len(heads) * hid_dim)                                        # block diagonal
+        row = 0
+        for i, (h, k) in enumerate(zip(heads, ks)):
+            w2[row:row + k, i * hid_dim:(i + 1) * hid_dim] = h[3].weight
+            row += k
+        logits = F.linear(hid, w2, torch.cat([h[3].bias for h in heads], 0))                      # (S*n, sum k)
+        n_soft = sum(1 for _, _, kind in _HEAD_SPECS if kind == "softmax" and prefix == "")       # SG_ heads: all sigmoid
+        k_soft = sum(ks[:n_soft])
+        assert all(k == ks[0] for k in ks[:n_soft])
+        parts = []
+        if n_soft:
+            parts.append(torch.softmax(logits[:, :k_soft].reshape(-1, n_soft, ks[0]), dim=2).reshape(-1, k_soft))
+        parts.append(torch.sigmoid(logits[:, k_soft:]))
+        full = torch.zeros([S, MNP, sum(ks)], device=feat.device, dtype=feat.dtype)
+        full[:, :n] = torch.cat(parts, 1).view(S, n, sum(ks))
+        outs, col = [], 0
+        for k in ks:
+            outs.append(full[:, :, col:col + k])
+            col += k
+        return outs
 
     def getloss(self, ):
         return

@@ -25,7 +25,7 @@ def _new(like: torch.Tensor, shape, dtype, fill=None) -> torch.Tensor:
     return torch.full(shape, fill, dtype=dtype, device=like.device)
 
 
-PRUNED_FPS_MIN_POINTS = 2048   # below this the plain kernel is already short (csrc/fps.hip)
+PRUNED_FPS_MIN_POINTS = 8192   # below this the plain kernel is as fast once the Morton sort (~15 launches) is counted
 
 
 class FarthestPointSampling(Function):
