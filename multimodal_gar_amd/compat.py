@@ -42,7 +42,9 @@ class _AliasFinder:
             mod = importlib.import_module(real)
         except ImportError:
             return None
-        sys.modules[fullname] = mod
+        # NOT registered in sys.modules here: importlib's _find_spec would then discard this spec in favour of the
+        # module's own __spec__ and execute the source file a second time; _Preloaded.create_module hands the
+        # already-imported module over and the import system registers it under the alias
         return importlib.util.spec_from_loader(fullname, _Preloaded(mod))
 
 

@@ -44,7 +44,12 @@ __device__ __forceinline__ size_t chan_off(long long e, int c, int C, int P) {
 }
 
 // ---- statistics: 4 B read per element -------------------------------------------------------
-// grid (nchunk, C).  partial[(c * nchunk + chunk) * 2 + {0,1}] = sum, sum of squares
+// grid (nchunk, C).  Cancellation-safe: every workgroup shifts its chunk by a chunk-local pivot (the mean of the
+// chunk's first <= 256 elements -- one per thread, so a single outlier moves it by 1/256 of itself) and accumulates
+// sum / sum of squares of (x - pivot) in fp32: the squares are of the order of the variance, not of mean^2.
+// partial[(c * nchunk + chunk) * 2 + {0,1}] = chunk mean, chunk M2 = sum (x - chunk mean)^2; bn_finalize_kernel merges
+// the chunks with Chan's parallel formula in double.  (With |mean| >> std a plain sum / sum-of-squares loses the
+// variance digits already in the fp32 partials: ADVICE r1.)
 __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__restrict__ x, int B, int C, int P, int chunk,
                                                                 float *__restrict__ partial) {
     __shared__ float scratch[BN_THREADS / 64];
@@ -52,17 +57,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__r
     const long long n = (long long)B * P;
     const long long e0 = (long long)blockIdx.x * chunk;
     const long long e1 = min(e0 + chunk, n);
+    const long long npiv = min((long long)BN_THREADS, e1 - e0);
+    float pv = threadIdx.x < npiv ? x[chan_off(e0 + threadIdx.x, c, C, P)] : 0.f;
+    const float pivot = block_sum(pv, scratch) / (float)npiv;
     float s = 0.f, q = 0.f;
     if ((P & 3) == 0) {
 #pragma unroll 4
         for (long long e = e0 + (long long)threadIdx.x * 4; e < e1; e += BN_THREADS * 4) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + chan_off(e, c, C, P));
+            float4 v = *reinterpret_cast<const float4 *>(x + chan_off(e, c, C, P));
+            v.x -= pivot; v.y -= pivot; v.z -= pivot; v.w -= pivot;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
     } else {
         for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
-            const float v = x[chan_off(e, c, C, P)];
+            const float v = x[chan_off(e, c, C, P)] - pivot;
             s += v;
             q += v * v;
         }
@@ -70,34 +79,41 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__r
     s = block_sum(s, scratch);
     q = block_sum(q, scratch);
     if (threadIdx.x == 0) {
-        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0] = s;
-        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1] = q;
+        const double nk = (double)(e1 - e0), sd = (double)s;
+        double m2 = (double)q - sd * sd / nk;
+        if (m2 < 0.0) m2 = 0.0;
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 0] = (float)((double)pivot + sd / nk);
+        partial[((size_t)c * gridDim.x + blockIdx.x) * 2 + 1] = (float)m2;
     }
 }
 
-// one wave per channel: combine the chunk sums in double (lanes stride over the chunks, then a
-// fixed-order shuffle tree), write mean / invstd, update running stats
+// one wave per channel: merge the chunk (count, mean, M2) triples in double (Chan et al.: M2 = sum M2_k +
+// sum n_k (mean_k - mean)^2; lanes stride over the chunks, fixed-order shuffle tree), write mean / invstd, update
+// running stats.  chunk = elements per chunk (the last one holds the remainder of n).
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
-__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, float eps,
-                                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                                         float *__restrict__ running_mean, float *__restrict__ running_var,
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ partial, int nchunk, int C, double n, int chunk,
+                                                         float eps, float momentum, float *__restrict__ mean,
+                                                         float *__restrict__ invstd, float *__restrict__ running_mean,
+                                                         float *__restrict__ running_var,
                                                          long long *__restrict__ num_batches_tracked,
                                                          float *__restrict__ var_out) {
     const int c = blockIdx.x;
-    double s = 0.0, q = 0.0;
+    auto count = [&](int i) { return i + 1 < nchunk ? (double)chunk : n - (double)chunk * (nchunk - 1); };
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nchunk; i += 64) s += count(i) * (double)partial[((size_t)c * nchunk + i) * 2 + 0];
+    const double m = wave_sum_f64(s) / n;
+    double q = 0.0;
     for (int i = threadIdx.x; i < nchunk; i += 64) {
-        s += (double)partial[((size_t)c * nchunk + i) * 2 + 0];
-        q += (double)partial[((size_t)c * nchunk + i) * 2 + 1];
+        const double d = (double)partial[((size_t)c * nchunk + i) * 2 + 0] - m;
+        q += (double)partial[((size_t)c * nchunk + i) * 2 + 1] + count(i) * d * d;
     }
-    s = wave_sum_f64(s);
     q = wave_sum_f64(q);
     if (threadIdx.x != 0) return;
-    const double m = s / n;
-    double var = q / n - m * m;
+    double var = q / n;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -119,8 +135,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
     const int row = blockIdx.x;
     const int c = row % C;
     const int sidx = stats_per_row ? row : c;   // per-sample statistics: mean / invstd have one entry per (sample, channel)
+    // y = (x - mean) * sc + beta, not x * sc + (beta - mean * sc): with |mean| >> std the second form rounds at the
+    // magnitude of mean * sc (x - mean is exact for x within a factor 2 of mean)
     const float sc = invstd[sidx] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[sidx] * sc;
+    const float mu = mean[sidx], sh = beta ? beta[c] : 0.f;
     const float *xr = x + (size_t)row * P;
     float *yr = y + (size_t)row * P;
     const int base = blockIdx.y * (BN_THREADS * 4 * BN_APPLY_V);
@@ -130,14 +148,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
             const int p = base + (u * BN_THREADS + threadIdx.x) * 4;
             if (p < P) {
                 float4 v = *reinterpret_cast<const float4 *>(xr + p);
-                v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
                 if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4 *>(yr + p) = v;
             }
         }
     } else {
         for (int p = base + threadIdx.x; p < min(P, base + BN_THREADS * 4 * BN_APPLY_V); p += BN_THREADS) {
-            float v = xr[p] * sc + sh;
+            float v = (xr[p] - mu) * sc + sh;
             yr[p] = RELU ? fmaxf(v, 0.f) : v;
         }
     }
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__r
     const int row = blockIdx.x;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const float mu = mean[c], sh = beta ? beta[c] : 0.f;
     const long long nq = (long long)M * G;
     const float *xr = x + (size_t)row * M * NS;
     float4 v[BN_MAX_V];
@@ -188,7 +206,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__r
         int bi = 0;
         if (live) {
             const int s0 = (int)(q % G) * 4;
-            const float a[4] = {v[u].x * sc + sh, v[u].y * sc + sh, v[u].z * sc + sh, v[u].w * sc + sh};
+            const float a[4] = {(v[u].x - mu) * sc + sh, (v[u].y - mu) * sc + sh, (v[u].z - mu) * sc + sh, (v[u].w - mu) * sc + sh};
 #pragma unroll
             for (int w = 0; w < 4; ++w)
                 if (a[w] > best) { best = a[w]; bi = s0 + w; }
@@ -220,12 +238,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restr
     if (m >= M) return;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
-    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const float mu = mean[c], sh = beta ? beta[c] : 0.f;
     const float *xr = x + ((size_t)row * M + m) * NS;
     float best = -__builtin_inff();
     int bi = 0;
     for (int s = 0; s < NS; ++s) {
-        const float a = xr[s] * sc + sh;
+        const float a = (xr[s] - mu) * sc + sh;
         if (a > best) { best = a; bi = s; }
     }
     out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
@@ -249,9 +267,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
     const long long e0 = (long long)blockIdx.x * BN_CHUNK;
     const long long e1 = min(e0 + BN_CHUNK, n);
     float s = 0.f, q = 0.f;
+    const float sc = is * g;
     auto acc = [&](float xv, float d) {
         const float xh = (xv - mu) * is;
-        if (RELU && !(xh * g + b > 0.f)) d = 0.f;
+        if (RELU && !((xv - mu) * sc + b > 0.f)) d = 0.f;   // the forward's expression, bit for bit
         s += d;
         q += d * xh;
     };
@@ -342,11 +361,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
     const float mu = mean[c], is = invstd[c];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const float m0 = coef[2 * c], m1 = coef[2 * c + 1];
-    const float k = g * is;
+    const float k = is * g;
     const size_t ro = (size_t)row * P;
     auto one = [&](float xv, float d) {
         const float xh = (xv - mu) * is;
-        if (RELU && !(xh * g + b > 0.f)) d = 0.f;
+        if (RELU && !((xv - mu) * k + b > 0.f)) d = 0.f;    // k = invstd * gamma as in the forward
         return k * (d - m0 - xh * m1);
     };
     if ((P & 3) == 0) {
@@ -442,7 +461,7 @@ BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, f
     { KtScope kt(KT_BN_STATS, st, 4.0 * (double)B * C * P);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, chunk, workspace);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, eps,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, chunk, eps,
                        momentum, mean, invstd, running_mean, running_var, num_batches_tracked, (float *)nullptr);
     return check_launch("bn_train_stats: launch failed");
 }
@@ -496,7 +515,7 @@ BN_API int mgar_bn_train_stats_grouped(const float *x, int G, int C, int P, floa
     { KtScope kt(KT_BN_STATS, st, 4.0 * (double)G * C * P);
     hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, rows), dim3(BN_THREADS), 0, st, x, 1, rows, P, chunk, workspace);
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rows), dim3(64), 0, st, workspace, nchunk, rows, (double)P, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(rows), dim3(64), 0, st, workspace, nchunk, rows, (double)P, chunk, eps, momentum, mean,
                        invstd, (float *)nullptr, (float *)nullptr, (long long *)nullptr, var);
     if (running_mean || running_var || num_batches_tracked)
         hipLaunchKernelGGL(bn_running_update_grouped_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, mean, var, G, C, (double)P,

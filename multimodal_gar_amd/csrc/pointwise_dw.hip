@@ -40,7 +40,7 @@ template <int OB, int IB>
 __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restrict__ x, const float *__restrict__ dy, int B, int Cin,
                                                            int Cout, int P, DwAct act, float *__restrict__ partial) {
     extern __shared__ float lds[];                 // [(OB + IB) * 32][DW_LD]
-    __shared__ float act_sc[IB * 32], act_sh[IB * 32];
+    __shared__ float act_sc[IB * 32], act_sh[IB * 32], act_mu[IB * 32];   // (x - mu) * sc + sh, as bn_apply_kernel
     float *sy = lds;                               // dY rows of this workgroup's output blocks
     float *sx = lds + OB * 32 * DW_LD;             // X rows of this workgroup's input blocks
     const int o_base = blockIdx.y * OB * 32, i_base = blockIdx.z * IB * 32;
@@ -48,13 +48,15 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
     if (has_act) {
         for (int r = threadIdx.x; r < IB * 32; r += 256) {
             const int ch = i_base + r;
-            float sc = 1.f, sh = 0.f;
+            float sc = 1.f, sh = 0.f, mu = 0.f;
             if (ch < Cin) {
                 sc = act.invstd[ch] * (act.gamma ? act.gamma[ch] : 1.f);
-                sh = (act.beta ? act.beta[ch] : 0.f) - act.mean[ch] * sc;
+                sh = act.beta ? act.beta[ch] : 0.f;
+                mu = act.mean[ch];
             }
             act_sc[r] = sc;
             act_sh[r] = sh;
+            act_mu[r] = mu;
         }
         __syncthreads();
     }
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
                 const int ch = is_y ? o_base + row : i_base + row - OB * 32;
                 float4 v = pre[u];
                 if (has_act && !is_y && ch < Cin && p0 + c4 < P) {   // padding stays zero
-                    const float sc = act_sc[row - OB * 32], sh = act_sh[row - OB * 32];
-                    v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                    const float sc = act_sc[row - OB * 32], sh = act_sh[row - OB * 32], mu = act_mu[row - OB * 32];
+                    v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
                     if (act.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 }
                 float *d = lds + row * DW_LD + c4;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
                 if (ch < cmax && p0 + cc < P) {
                     v = (is_y ? dy : x)[((size_t)b * cmax + ch) * P + p0 + cc];
                     if (has_act && !is_y) {
-                        v = v * act_sc[row - OB * 32] + act_sh[row - OB * 32];
+                        v = (v - act_mu[row - OB * 32]) * act_sc[row - OB * 32] + act_sh[row - OB * 32];
                         if (act.relu) v = fmaxf(v, 0.f);
                     }
                 }

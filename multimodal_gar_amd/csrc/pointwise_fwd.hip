@@ -48,7 +48,7 @@ template <int OB>
 __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
     constexpr int PF_KC = PfSlab<OB>::KC, KS = PF_KC / 2;
     constexpr int WLD = OB == 1 ? 32 : 96;  // LDS row stride of W: the two half-waves hit disjoint banks
-    extern __shared__ float lds[];          // [nkc*16][WLD] weights, then [nkc*16][2] (sc, sh)
+    extern __shared__ float lds[];          // [nkc*16][WLD] weights, then [nkc*16][4] (sc, sh, mu, -)
     const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
     float *wl = lds;
     float *act = lds + (size_t)nkc * PF_KC * WLD;
@@ -57,13 +57,13 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
         wl[e] = (ch < a.Cin && o < a.Cout) ? a.w[(size_t)o * a.w_rs + (size_t)ch * a.w_cs] : 0.f;
     }
     for (int ch = threadIdx.x; ch < nkc * PF_KC; ch += 256) {
-        float sc = 1.f, sh = 0.f;
+        float sc = 1.f, sh = 0.f, mu = 0.f;   // act(v) = (v - mu) * sc + sh: the arithmetic of bn_apply_kernel
         if (a.mean && ch < a.Cin) {
             sc = a.invstd[ch] * (a.gamma ? a.gamma[ch] : 1.f);
-            sh = (a.beta ? a.beta[ch] : 0.f) - a.mean[ch] * sc;
+            sh = a.beta ? a.beta[ch] : 0.f;
+            mu = a.mean[ch];
         }
-        act[2 * ch] = sc;
-        act[2 * ch + 1] = sh;
+        *reinterpret_cast<float4 *>(act + 4 * ch) = make_float4(sc, sh, mu, 0.f);
     }
     __syncthreads();
 
@@ -106,8 +106,9 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
             const int ch = kc * PF_KC + 2 * ks + h;
             float4 v = buf[ks];
             if (has_act) {
-                const float sc = act[2 * ch], sh = act[2 * ch + 1];
-                v.x = v.x * sc + sh; v.y = v.y * sc + sh; v.z = v.z * sc + sh; v.w = v.w * sc + sh;
+                const float4 ac = *reinterpret_cast<const float4 *>(act + 4 * ch);
+                const float sc = ac.x, sh = ac.y, mu = ac.z;
+                v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
                 if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (ch >= a.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);   // padding channels stay zero (W is zero there too)
             }
@@ -153,7 +154,7 @@ template <int OB>
 static void launch_pf(const PfArgs &a, hipStream_t st) {
     constexpr int WLD = OB == 1 ? 32 : 96, PF_KC = PfSlab<OB>::KC;
     const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
-    const int lds = nkc * PF_KC * (WLD + 2) * (int)sizeof(float);
+    const int lds = nkc * PF_KC * (WLD + 4) * (int)sizeof(float);
     static int attr_lds = 0;
     if (lds > 65536 && lds > attr_lds) {
         (void)hipFuncSetAttribute((const void *)pointwise_fwd_kernel<OB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -1,0 +1,213 @@
+"""Parity holes named by the round-1 review:
+  * the voxel route (VoxelQueryAndGrouping, NeighborVoxelSAModuleMSG, VoxelRCNNHead, stack group_points_grad reached
+    through them) in TRAIN mode, forward AND backward, HIP kernels vs the oracle backend;
+  * the RoI-grid lift at config c3's actor count (A = 32, 6^3 grid, P = 16 384) against the oracle;
+  * BatchNorm statistics when |mean| >> std (one-pass sum / sum-of-squares cancels).
+"""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from param_fill import fill_deterministic  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, rtol=1e-4, atol=1e-5, what=""):
+    a = a.detach().double().cpu(); b = b.detach().double().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-12
+    err = (a - b).abs().max().item()
+    assert err <= atol + rtol * scale, "%s: max err %g vs scale %g" % (what, err, scale)
+
+
+def _no_dropout(module):
+    for m in module.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+            m.dropout = 0.0
+
+
+def scene(seed, b, n, a=4):
+    from multimodal_gar_amd import synthetic as S
+    sc = S.scene_batch(seed, b, a, n)
+    return torch.from_numpy(np.ascontiguousarray(sc["points"])), torch.from_numpy(sc["bboxes3d"])
+
+
+def test_voxel_detector_train_forward_backward_vs_oracle_backend():
+    """MeanVFE -> trunk -> VoxelRCNNHead in train mode: pooled features, gradient of the raw voxel payload, every
+    parameter gradient and the BatchNorm running statistics, device vs oracle backend."""
+    from multimodal_gar_amd import workload as W
+    from multimodal_gar_amd.pcdet.models import build_network
+    from oracle.cpu_backend import use_cpu_oracle
+    ds = W.SyntheticDataset()
+    points, b3 = scene(3, 2, 4096)
+    net = fill_deterministic(build_network(W.lidar_model_cfg(4096, "voxel"), 1, ds), seed=9).train()
+    _no_dropout(net)
+    res = {}
+    for dev in ("cuda", "cpu"):
+        m = copy.deepcopy(net).to(dev)
+        data = W.voxelize_batch(points.to(dev), ds)
+        data["voxels"] = data["voxels"].clone().requires_grad_(True)
+        data["gt_boxes"] = b3[:, :4, :].contiguous().to(dev)
+        ctx = use_cpu_oracle() if dev == "cpu" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            out = m(data)
+            pooled, shared = out["pooled_features"], out["shared_feature"]
+            cot = torch.linspace(-1, 1, pooled.numel(), device=dev).view(pooled.shape)
+            ((pooled * cot).sum() + (shared * shared).mean()).backward()
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+        res[dev] = (pooled, data["voxels"].grad, {n: p.grad for n, p in m.named_parameters()},
+                    {n: b for n, b in m.named_buffers() if b.is_floating_point()})
+    g, c = res["cuda"], res["cpu"]
+    assert g[0].shape == (8, 216, 96) and c[0].abs().sum() > 0
+    close(g[0], c[0], what="pooled_features")
+    close(g[1], c[1], rtol=1e-3, what="d voxels")
+    assert c[1].abs().sum() > 0
+    assert set(g[2]) == set(c[2])
+    n_checked = 0
+    for n in c[2]:
+        assert (g[2][n] is None) == (c[2][n] is None), n
+        if c[2][n] is not None:
+            close(g[2][n], c[2][n], rtol=1e-3, what="grad " + n)
+            n_checked += 1
+    assert n_checked >= 30
+    for n in c[3]:
+        close(g[3][n], c[3][n], rtol=1e-4, what="buffer " + n)
+
+
+def test_clip_model_voxel_route_train_backward_vs_oracle_backend():
+    """ClipModel(route='voxel'): forward + backward of the whole clip model through the voxel RoI pooling kernels."""
+    from multimodal_gar_amd import workload as W
+    from oracle.cpu_backend import use_cpu_oracle
+    torch.manual_seed(0)
+    model = fill_deterministic(W.ClipModel(4, 2048, route="voxel"), seed=13).train()
+    _no_dropout(model)
+    batch = W.make_batch(8, 1, 2, 4, 2048, 64, 96, torch.device("cpu"))
+    cm = copy.deepcopy(model)
+    with use_cpu_oracle():
+        want = cm(batch)
+        W.synthetic_loss(want).backward()
+    gm = copy.deepcopy(model).cuda()
+    gb = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    got = gm(gb)
+    W.synthetic_loss(got).backward()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(got, want)):
+        close(a, b, rtol=2e-3, atol=1e-5, what="output %d" % i)
+    gp, cp = dict(gm.named_parameters()), dict(cm.named_parameters())
+    checked = 0
+    for n, p in cp.items():
+        if p.grad is None:
+            assert gp[n].grad is None, n
+            continue
+        # train-mode BatchNorm over a handful of actors amplifies fp32 summation-order noise
+        close(gp[n].grad, p.grad, rtol=2e-2, atol=1e-6, what="grad " + n)
+        checked += 1
+    assert checked > 100
+    lidar = [n for n in cp if "LiDAR_backbone.model.roi_head.roi_grid_pool_layers" in n and cp[n].grad is not None]
+    assert len(lidar) >= 20, "voxel RoI pooling parameters must receive gradients"
+
+
+def test_roi_grid_lift_at_c3_actor_count_vs_oracle():
+    """PointGridRoIHead (StackSAModuleMSG on the 6^3 grid of every actor box) at config c3's per-frame size: A = 32
+    actors, P = 16 384 points, 2 frames -> 13 824 queries against 3 radii; forward and backward vs the oracle backend."""
+    from multimodal_gar_amd import workload as W
+    from multimodal_gar_amd.pcdet.models.roi_heads.point_grid_head import PointGridRoIHead
+    from oracle.cpu_backend import use_cpu_oracle
+    f, a, p, c = 2, 32, 16384, 128
+    points, b3 = scene(11, f, p, a)
+    cfg = W.lidar_model_cfg(p)["ROI_HEAD"]
+    head = fill_deterministic(PointGridRoIHead(c, cfg), seed=5).train()
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(f * p, c, generator=g)
+    bidx = torch.arange(f, dtype=torch.float32).view(f, 1, 1).expand(f, p, 1)
+    coords = torch.cat([bidx, points[..., :3]], -1).view(f * p, 4)
+    res = {}
+    for dev in ("cuda", "cpu"):
+        m = copy.deepcopy(head).to(dev)
+        fx = feats.to(dev).clone().requires_grad_(True)
+        data = {"batch_size": f, "gt_boxes": b3[:, :a, :].contiguous().to(dev), "point_coords": coords.to(dev),
+                "point_features": fx, "point_batch_cnt": torch.full((f,), p, dtype=torch.int32, device=dev)}
+        ctx = use_cpu_oracle() if dev == "cpu" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            pooled = m(data)["pooled_features"]
+            cot = torch.linspace(-1, 1, pooled.numel(), device=dev).view(pooled.shape)
+            (pooled * cot).sum().backward()
+        finally:
+            if ctx:
+                ctx.__exit__(None, None, None)
+        res[dev] = (pooled, fx.grad, [q.grad for q in m.parameters()])
+    assert res["cuda"][0].shape == (f * a, 216, 96)
+    close(res["cuda"][0], res["cpu"][0], what="pooled")
+    close(res["cuda"][1], res["cpu"][1], rtol=1e-3, what="d features")
+    for x, y in zip(res["cuda"][2], res["cpu"][2]):
+        close(x, y, rtol=1e-3, what="d param")
+
+
+@pytest.mark.parametrize("shape", [(4, 8, 70000), (3, 5, 33, 16), (1, 6, 1023)])
+def test_batchnorm_large_mean_small_std_matches_float64(shape):
+    """x ~ N(100, 0.01^2): a one-pass fp32 sum / sum-of-squares loses the variance; the chunk-pivot + Chan merge of
+    csrc/bn_act.hip must agree with a float64 BatchNorm for y, the running statistics and dx (plain, fused max-pool
+    and fused [BN -> ReLU -> conv] routes)."""
+    from multimodal_gar_amd import bn_ops
+    torch.manual_seed(1)
+    c = shape[1]
+    x = (100.0 + 0.01 * torch.randn(shape)).cuda()
+    bn = (torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm1d)(c).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.2, 0.3, c))
+    ref = copy.deepcopy(bn).double()
+    xr = x.double().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    cot = torch.linspace(-1, 1, yr.numel(), device="cuda", dtype=torch.float64).view(yr.shape)
+    (yr * cot).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    y = bn_ops.bn_act(xg, bn, True)
+    (y * cot.float()).sum().backward()
+    # the input itself is quantised at 7.6e-6 / 0.01 = 7.6e-4 standard deviations: y carries that, nothing more
+    close(y, yr, rtol=0, atol=2e-3, what="y")
+    close(bn.running_mean, ref.running_mean, rtol=1e-6, what="running_mean")
+    close(bn.running_var, ref.running_var, rtol=2e-3, atol=1e-9, what="running_var")
+    close(xg.grad, xr.grad, rtol=5e-3, what="dx")
+    close(bn.weight.grad, ref.weight.grad, rtol=5e-3, what="dgamma")
+    if len(shape) == 4:
+        bn2 = copy.deepcopy(bn); bn2.weight.grad = None
+        ref2 = copy.deepcopy(bn).double()
+        xr2 = x.double().requires_grad_(True)
+        pr = torch.relu(ref2(xr2)).max(dim=3).values
+        pc = torch.linspace(-1, 1, pr.numel(), device="cuda", dtype=torch.float64).view(pr.shape)
+        (pr * pc).sum().backward()
+        xg2 = x.clone().requires_grad_(True)
+        pooled = bn_ops.bn_act_maxpool(xg2, bn2, True)
+        (pooled * pc.float()).sum().backward()
+        close(pooled, pr, rtol=0, atol=2e-3, what="pooled")
+        close(xg2.grad, xr2.grad, rtol=5e-3, atol=1e-4 * xr2.grad.abs().max().item(), what="dx after max-pool")
+
+
+def test_batchnorm_outlier_in_first_element_keeps_variance():
+    """A single large outlier at the head of a chunk must not poison the chunk pivot (it is the mean of 256 elements)."""
+    from multimodal_gar_amd import bn_ops
+    torch.manual_seed(2)
+    x = torch.randn(2, 3, 200000)
+    x[0, :, 0] = 1.0e4
+    x = x.cuda()
+    bn = torch.nn.BatchNorm1d(3).cuda().train()
+    ref = copy.deepcopy(bn).double()
+    yr = ref(x.double())
+    y = bn_ops.bn_act(x, bn, False)
+    close(bn.running_var, ref.running_var, rtol=1e-4, what="running_var")
+    close(y, yr, rtol=1e-5, atol=1e-5, what="y")
