@@ -32,15 +32,31 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak, same guide
 
 
+# BASELINE.json configs that run on one rank.  c3 is the metric's configuration (and c4 = c3 sharded over ranks);
+# c2 / c5 are the bf16 configurations (feature payloads and GEMMs in bf16, coordinates / distances / indices fp32 / int32,
+# SURVEY.md section 8 header) and are forward passes.
+CONFIGS = {
+    "c3": dict(clips=8, frames=15, actors=32, points=16384, precision="fp32", mode="train"),
+    "c2": dict(clips=4, frames=15, actors=16, points=8192, precision="bf16", mode="forward"),
+    "c5": dict(clips=8, frames=15, actors=128, points=65536, precision="bf16", mode="forward"),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=8, help="GLOBAL clip batch (config c3/c4)")
-    ap.add_argument("--frames", type=int, default=15)
-    ap.add_argument("--actors", type=int, default=32)
-    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration: c3 = the metric's (fp32 fwd+bwd+Adam, 8 clips x 32 actors x 16 384 pts); "
+                         "c2 = bf16 forward, 4 clips x 16 actors x 8 192 pts; c5 = bf16 forward, 128 actors x 65 536 pts")
+    ap.add_argument("--clips", type=int, default=None, help="GLOBAL clip batch (default: the configuration's)")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--actors", type=int, default=None)
+    ap.add_argument("--points", type=int, default=None)
+    ap.add_argument("--precision", default=None, choices=["fp32", "bf16"])
+    ap.add_argument("--mode", default=None, choices=["train", "forward"],
+                    help="train = forward + backward + Adam; forward = train-mode forward only (batch-statistics BatchNorm)")
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--route", default="pointnet2", choices=["pointnet2", "voxel"])
@@ -55,11 +71,16 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every kernel from the host instead of replaying forward + backward from a HIP graph "
                          "(torch.cuda.CUDAGraph; default on: 4-9 %% per step, more on ranks that hold a single clip)")
+    ap.add_argument("--require-graph", action="store_true", help="fail instead of falling back to eager launches when capture fails")
     ap.add_argument("--ddp-wrapper", action="store_true",
                     help="eager DistributedDataParallel (bucketed all-reduce overlapped with backward) instead of one flattened "
                          "gradient all-reduce after the backward; implies --no-graph (DDP hooks cannot be captured)")
     ap.add_argument("--phases", action="store_true", help="print a synchronised per-phase timing of one step")
-    return ap.parse_args()
+    args = ap.parse_args()
+    for k, v in CONFIGS[args.config].items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
 
 
 # --------------------------------------------------------------------------------------------
@@ -71,47 +92,84 @@ def parse():
 # is not perturbed by ~3 000 event records per step.
 # --------------------------------------------------------------------------------------------
 MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel")
+PAIR_KERNELS = ("fps_kernel", "ball_query_kernel", "three_nn_kernel")   # (query, point) scans: VALU-bound, pair evaluations of 8 flop
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # rocprofv3 --pmc passes, see profiles/README.md
 
 
+def pmc_traffic(clips_local):
+    """-> ({kernel: bytes per launch}, source tag).  The PMC figures are a committed measurement (tools/pmc_traffic.py on
+    two rocprofv3 --pmc passes), NOT taken in this run: a figure is attached only for the per-rank batch it was measured
+    at and only while the kernel's .hip source still has the sha it had then."""
+    from multimodal_gar_amd.op_timer import source_sha16
+    if not os.path.exists(PMC_TRAFFIC_FILE):
+        return {}, None
+    try:
+        pmc = json.load(open(PMC_TRAFFIC_FILE))
+    except (OSError, ValueError):
+        return {}, None
+    if pmc.get("clips_per_gpu") != clips_local:
+        return {}, None
+    shas = pmc.get("source_sha16", {})
+    ok = {k: v for k, v in pmc.get("per_launch_bytes", {}).items() if shas.get(k) and shas.get(k) == source_sha16(k)}
+    tag = "profiles/pmc_hbm_traffic.json@%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; not measured in this run)" \
+        % pmc.get("commit", "unknown")
+    return ok, tag
+
+
 def kernel_rooflines(step, batch, frames, n_points, clips_local=None):
-    """-> list of per-kernel roofline dicts for one training step, the dominant (largest total time) first."""
+    """One extra, instrumented step (eager, ONE stream) -> (rows, accounting).  rows: one roofline dict per hand-written
+    kernel (events inside the library, csrc/errors.hip) AND per library op / shape (convolutions and GEMMs with their
+    FLOPs against the MFMA peak of their dtype; multimodal_gar_amd/op_timer.py), the largest total time first.
+    accounting: where the whole step goes, by class."""
     from multimodal_gar_amd import _lib as L
+    from multimodal_gar_amd.op_timer import AtenOpTimer
     # one stream for this step: with the RGB branch on its side stream two kernels share the chip and the time
     # between a kernel's two events is no longer the time that kernel needs
     overlap, step.module.overlap_branches = step.module.overlap_branches, False
     L.kernel_timers(enable=True)
     L.kernel_timers()                       # drop anything recorded so far
-    step.run_eager(batch)
     torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with AtenOpTimer() as lib_ops:
+        step.run_eager(batch)
+        torch.cuda.synchronize()
+    step_ms = (time.perf_counter() - t0) * 1e3
     L.kernel_timers(enable=False)
     step.module.overlap_branches = overlap
     table = L.kernel_timers()
-    traffic = {}
-    if os.path.exists(PMC_TRAFFIC_FILE):
-        try:
-            pmc = json.load(open(PMC_TRAFFIC_FILE))
-            # measured per launch at one per-rank batch size: only valid for that one
-            traffic = pmc.get("per_launch_bytes", {}) if pmc.get("clips_per_gpu") == clips_local else {}
-        except (OSError, ValueError):
-            traffic = {}
+    traffic, traffic_src = pmc_traffic(clips_local)
     res = []
     for name, (ms, launches, nbytes, flops) in table.items():
         gbs = nbytes / ms / 1e6 if ms > 0 else 0.0
-        row = {"kernel": name, "launches_per_step": launches, "ms_per_step": ms, "avg_launch_ms": ms / launches,
-               "algorithmic_bytes_per_launch": nbytes / launches, "traffic": traffic.get(name)}
+        row = {"kernel": name, "class": "hand_written", "launches_per_step": launches, "ms_per_step": ms, "avg_launch_ms": ms / launches,
+               "algorithmic_bytes_per_launch": nbytes / launches, "traffic": traffic.get(name),
+               "traffic_source": traffic_src if name in traffic else None}
         if name in MFMA_KERNELS:
             tf = flops / ms / 1e9 if ms > 0 else 0.0
             row.update({"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
                         "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
         else:
             row.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
-        if name == "fps_kernel" and flops:
-            row["pair_evals_per_s"] = flops / 8.0 / (ms * 1e-3)       # 8 flop per pair evaluation
+        if name in PAIR_KERNELS and flops:
+            # these scans move almost nothing (the HBM fraction above is the contract's figure and says so); what bounds
+            # them is fp32 VALU work: pair evaluations per second and their share of the vector peak
+            row["pair_evals_per_s"] = flops / 8.0 / (ms * 1e-3)
             row["valu_frac"] = flops / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS
         res.append(row)
+    lib_rows, lib_totals = lib_ops.table()
+    res += lib_rows
     res.sort(key=lambda r: -r["ms_per_step"])
-    return res
+    for r in res:
+        if r.get("frac", 0.0) > 1.0:
+            r["suspect"] = "fraction above the peak: the algorithmic figure over-counts what this kernel must move"
+            log("WARNING: %s reports %.2f of its roofline" % (r["kernel"], r["frac"]))
+    hand = sum(ms for ms, _, _, _ in table.values())
+    accounting = {"hand_written_kernels_ms": hand, "library_conv_ms": lib_totals["conv"], "library_gemm_ms": lib_totals["gemm"],
+                  "torch_elementwise_copy_reduce_ms": lib_totals["other"],
+                  "sum_ms": hand + sum(lib_totals.values()), "instrumented_step_wall_ms": step_ms,
+                  "note": "one eager single-stream step with events around every kernel / aten op (slower than the timed "
+                          "graph-replayed two-stream steps; its purpose is attribution)"}
+    return res, accounting
 
 
 # --------------------------------------------------------------------------------------------
@@ -133,19 +191,24 @@ def cpu_baseline(args):
     dev = torch.device("cpu")
     sample_frames = min(3, args.frames)
     batch = W.make_batch(7, 1, sample_frames, args.actors, args.points, args.height, args.width, dev)
+    passes = 3
     with use_cpu_oracle():
         step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route)
         step.run(batch)                                     # warm-up (allocator, oneDNN primitive cache)
-        t0 = time.time(); step.module.rgb_tokens(batch["images"], batch["bboxes"]); t_rgb = time.time() - t0
-        t0 = time.time(); step.run(batch); t_all = time.time() - t0
+        t_rgbs, t_alls = [], []
+        for _ in range(passes):
+            t0 = time.time(); step.module.rgb_tokens(batch["images"], batch["bboxes"]); t_rgbs.append(time.time() - t0)
+            t0 = time.time(); step.run(batch); t_alls.append(time.time() - t0)
+    t_rgb, t_all = sorted(t_rgbs)[passes // 2], sorted(t_alls)[passes // 2]       # medians
     t_frames = max(t_all - t_rgb, 1e-6)
     scale = args.frames / sample_frames
-    clip_s = (t_rgb + t_frames) * scale
-    return {"value": 1.0 / clip_s, "unit": "clips/sec", "cores": cores, "kind": "port",
-            "sample": "1 clip x %d frames (of %d) at full A=%d, P=%d, %dx%d, fwd+bwd+Adam, after one warm-up pass; "
-                      "time scaled x%.0f to a %d-frame clip; %.1f s measured (I3D part %.1f s)"
-                      % (sample_frames, args.frames, args.actors, args.points, args.height, args.width, scale,
-                         args.frames, t_all, t_rgb)}
+    clip_s = (t_rgb + t_frames) * scale          # the sample clip has sample_frames RGB frames AND LiDAR frames: both parts scale
+    return {"value": 1.0 / clip_s, "unit": "clips/sec", "cores": cores, "kind": "port", "timed_passes": passes,
+            "sample": "1 clip x %d frames (of %d) at full A=%d, P=%d, %dx%d, fwd+bwd+Adam: 1 warm-up + %d timed passes, median; "
+                      "time scaled x%.0f to a %d-frame clip; "
+                      "step %.1f s (min %.1f, max %.1f), I3D part %.1f s"
+                      % (sample_frames, args.frames, args.actors, args.points, args.height, args.width, passes, scale,
+                         args.frames, t_all, min(t_alls), max(t_alls), t_rgb)}
 
 
 def log(msg):
@@ -215,8 +278,13 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find   # MIOpen find mode for the I3D convolutions
     log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
     use_graph = not args.no_graph and not args.ddp_wrapper
-    step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp,
-                       manual_allreduce=not args.ddp_wrapper)
+    if args.mode == "train":
+        if args.precision != "fp32":
+            raise SystemExit("bench.py: the backward runs in fp32 only (bf16 is a forward configuration: c2 / c5)")
+        step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp,
+                           manual_allreduce=not args.ddp_wrapper)
+    else:
+        step = W.ForwardStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, precision=args.precision)
     # frozen I3D on a side stream (no autograd there: DDP-safe).  Only together with the HIP graph: issued eagerly from
     # the host the two-stream step measured 362 ms against 269 ms on one stream (and 257 ms as a graph on two).
     step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
@@ -235,7 +303,9 @@ def main():
         try:
             step.capture(batch)
             log("forward + backward captured into a HIP graph")
-        except Exception as e:   # noqa: BLE001 -- any capture problem: fall back to host-issued launches, same arithmetic
+        except RuntimeError as e:   # what torch raises for an op that cannot be captured / a failed HIP call during capture
+            if args.require_graph:
+                raise
             step.graph = None
             step.module.overlap_branches = False
             log("HIP-graph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, str(e).splitlines()[0][:200]))
@@ -258,34 +328,48 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.clips * args.steps / elapsed
 
-    roof, kernels, cpu = None, None, None
+    roof, kernels, cpu, accounting = None, None, None, None
     if not args.no_kernel_timing:
         if rank == 0:
-            kernels = kernel_rooflines(step, batch, clips_local * args.frames, args.points, clips_local)
-            roof = {k: kernels[0][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_per_step",
-                                               "ms_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch")}
-            log("dominant hand-written kernel: %s, %.2f ms/step in %d launches, %.0f %s (%.1f %% of peak)"
+            kernels, accounting = kernel_rooflines(step, batch, clips_local * args.frames, args.points, clips_local)
+            # the dominant kernel of the WHOLE step (hand-written or library) that has a roofline; and, beside it, the
+            # dominant hand-written one (the kernels this repo can tune)
+            dom = next(r for r in kernels if "bound" in r and "frac" in r)
+            own = next((r for r in kernels if r.get("class") == "hand_written"), None)
+            keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "class", "launches_per_step",
+                    "ms_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch", "flops_per_launch", "dtype")
+            roof = {k: dom[k] for k in keys if k in dom}
+            roof.setdefault("traffic", None)
+            if own is not None and own is not dom:
+                roof["dominant_hand_written"] = {k: own[k] for k in keys if k in own}
+            log("dominant kernel of the step: %s, %.2f ms/step in %d launches, %.0f %s (%.1f %% of peak)"
                 % (roof["kernel"], roof["ms_per_step"], roof["launches_per_step"], roof["achieved"], roof["unit"], 100 * roof["frac"]))
+            log("step accounting (ms): %s" % {k: (round(v, 1) if isinstance(v, float) else v) for k, v in accounting.items() if k != "note"})
         else:
             step.run_eager(batch)    # the extra (instrumented on rank 0) step is collective under DDP
         barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
         cpu = cpu_baseline(args)
     if rank == 0:
+        what = "fwd+bwd" if args.mode == "train" else "fwd"
         line = {
-            "metric": "clips/sec (fwd+bwd) at 32 actors x 16k pts x 15 frames",
+            "metric": "clips/sec (%s) at %d actors x %dk pts x %d frames" % (what, args.actors, args.points // 1024, args.frames),
             "value": value, "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "c3: %d clips x %d frames x %d actors x %d pts, %dx%d RGB, fp32 fwd+bwd+Adam, "
-                                   "LiDAR route %s, GAT %s" % (args.clips, args.frames, args.actors, args.points,
-                                                                args.height, args.width, args.route,
-                                                                "off" if args.no_gat else "on"),
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": "%s: %d clips x %d frames x %d actors x %d pts, %dx%d RGB, %s %s, "
+                                   "LiDAR route %s, GAT %s" % (args.config, args.clips, args.frames, args.actors, args.points,
+                                                                args.height, args.width, args.precision,
+                                                                "fwd+bwd+Adam" if args.mode == "train" else
+                                                                "train-mode forward (feature payloads + GEMMs bf16; xyz, distances, "
+                                                                "indices, BN statistics fp32/int32)" if args.precision == "bf16"
+                                                                else "train-mode forward",
+                                                                args.route, "off" if args.no_gat else "on"),
                        "global_clips": args.clips, "clips_per_gpu": clips_local, "parallelism": "dp%d" % world,
                        "launch": "hip_graph" if step.graph is not None else "eager",
                        "gradient_exchange": "none" if world == 1 else ("ddp_bucketed" if args.ddp_wrapper else "flat_allreduce"),
                        "trainable_params": W.trainable_parameter_count(step.module)},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "step_accounting": accounting, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if ddp:

@@ -46,6 +46,9 @@ int mgar_ktimer_count(void);
 const char *mgar_ktimer_name(int id);
 int mgar_ktimer_read(int id, double *total_ms, long long *launches, double *total_bytes, double *total_flops,
                      int reset);
+/* adds `flops` to kernel id's total while the timers are on: for stacked-layout launches whose per-sample counts
+ * live on the device (the library cannot know sum_i M_i * N_i), the instrumenting caller supplies the work */
+int mgar_ktimer_add_flops(int id, double flops);
 
 /* ======================= pointnet2_batch: (B, N, 3) / (B, C, N) ======================= */
 
@@ -362,6 +365,70 @@ int mgar_gatv2_fwd(int n_nodes, int H, int C, const int *rowptr, const int *col,
 int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
                    const float *xr, const float *att, float slope, const float *edge_scale, const float *alpha,
                    const float *grad_out, float *grad_xl, float *grad_xr, float *grad_att, void *stream);
+
+/* ============================ bf16 feature payloads (BASELINE configs c2, c5) ============================
+ * The reference's kernels are fp32 + int32 only.  For the bf16 configurations SURVEY.md section 8 keeps coordinates,
+ * distances, indices and BatchNorm statistics in fp32 / int32 and stores only FEATURE PAYLOADS (and runs the GEMMs) in
+ * bf16.  Every entry point below is the twin of the fp32 entry point of the same name without the suffix: same
+ * arguments, same semantics, but the pointers named in the comment address bf16 elements (torch.bfloat16 storage,
+ * passed as void*).  Arithmetic is fp32 inside the kernels (elements are widened on load and rounded to nearest even
+ * on store), so index outputs are bit-identical to the fp32 path by construction and features agree with it to
+ * bf16 rounding (2^-9 relative per stored tensor).  Query ops (ball / voxel query, FPS, three_nn) have no twin: they
+ * never touch a payload. */
+/* features, out */
+int mgar_query_group_batch_fwd_bf16(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                    const void *features, const int *idx, void *out, void *stream);
+int mgar_query_group_stack_fwd_bf16(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                    const float *new_xyz, const int *new_xyz_batch_cnt, const void *features,
+                                    const int *idx, void *out, void *stream);
+/* zf, rel_out, y_out (wx stays fp32) */
+int mgar_query_group_proj_batch_fwd_bf16(int b, int c, int n, int npoints, int nsample, const float *xyz,
+                                         const float *new_xyz, const void *zf, const float *wx, const int *idx,
+                                         void *rel_out, void *y_out, void *stream);
+int mgar_query_group_proj_stack_fwd_bf16(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                         const float *new_xyz, const int *new_xyz_batch_cnt, const void *zf, int zf_ld,
+                                         const float *wx, const int *idx, void *rel_out, void *y_out, void *stream);
+/* x (statistics, affine, running statistics: fp32) */
+int mgar_bn_train_stats_bf16(const void *x, int B, int C, int P, float eps, float momentum, float *workspace,
+                             float *mean, float *invstd, float *running_mean, float *running_var,
+                             long long *num_batches_tracked, void *stream);
+int mgar_bn_train_stats_grouped_bf16(const void *x, int G, int C, int P, float eps, float momentum, float *workspace,
+                                     float *mean, float *invstd, float *running_mean, float *running_var,
+                                     long long *num_batches_tracked, void *stream);
+/* x, y */
+int mgar_bn_act_fwd_bf16(const void *x, int B, int C, int P, const float *mean, const float *invstd,
+                         const float *gamma, const float *beta, int relu, void *y, void *stream);
+int mgar_bn_act_fwd_grouped_bf16(const void *x, int G, int C, int P, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, int relu, void *y, void *stream);
+/* x, out, xarg */
+int mgar_bn_act_maxpool_fwd_bf16(const void *x, int B, int C, int M, int nsample, const float *mean,
+                                 const float *invstd, const float *gamma, const float *beta, int relu, void *out,
+                                 unsigned char *arg, void *xarg, void *stream);
+/* dy, x, dx (dgamma, dbeta fp32) */
+int mgar_bn_act_bwd_bf16(const void *dy, const void *x, int B, int C, int P, const float *mean, const float *invstd,
+                         const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
+                         float *dbeta, void *dx, void *stream);
+/* dpool, pooled, x, xarg, dx */
+int mgar_bn_act_maxpool_bwd_bf16(const void *dpool, const void *pooled, const unsigned char *arg, const void *x,
+                                 const void *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd,
+                                 const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta,
+                                 void *dx, void *stream);
+/* x, y (w and the BatchNorm vectors fp32; fp32 accumulation) */
+int mgar_pointwise_conv_fwd_bf16(const void *x, int B, int Cin, int P, const float *w, int w_row_stride,
+                                 int w_col_stride, int Cout, const float *in_mean, const float *in_invstd,
+                                 const float *in_gamma, const float *in_beta, int in_relu, void *y, void *stream);
+/* points / features, out (weight fp32) */
+int mgar_three_interpolate_batch_bf16(int b, int c, int m, int n, const void *points, const int *idx,
+                                      const float *weight, void *out, void *stream);
+int mgar_three_interpolate_stack_bf16(int N, int C, const void *features, const int *idx, const float *weight,
+                                      void *out, void *stream);
+/* x, y */
+int mgar_maxpool3d_same_fwd_bf16(const void *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh,
+                                 int sw, void *y, void *stream);
+/* input, out (rois fp32) */
+int mgar_roi_align_fwd_bf16(const void *input, int N, int C, int H, int W, const float *rois, int K,
+                            int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
+                            void *out, void *stream);
 
 #ifdef __cplusplus
 }

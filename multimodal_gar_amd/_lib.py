@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -56,6 +56,7 @@ _PROTOS = {
     "mgar_rowmajor_dw_workspace_floats": [_LL, _I, _I],
     "mgar_ktimer_enable": [_I],
     "mgar_ktimer_count": [],
+    "mgar_ktimer_add_flops": [_I, ctypes.c_double],
     "mgar_ktimer_read": [_I, _P, _P, _P, _P, _I],
     "mgar_rowmajor_dw": [_P, _I, _P, _I, _LL, _I, _I, _P, _P, _P],
     "mgar_bn_workspace_floats": [_I, _I, _I],
@@ -78,6 +79,14 @@ _PROTOS = {
     "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P],
     "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
 }
+# bf16-payload twins (include/mgar_ops.h, last section): identical argument lists
+for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_query_group_proj_batch_fwd",
+           "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
+           "mgar_bn_act_fwd_grouped", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
+           "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_stack",
+           "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd"):
+    _PROTOS[_n + "_bf16"] = _PROTOS[_n]
+BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 
 _fns = {}
 for _name, _args in _PROTOS.items():
@@ -111,6 +120,20 @@ def dev_ptr(t, dtype=None):
 
 def fptr(t):
     return dev_ptr(t, torch.float32)
+
+
+def pptr(t, dtype):
+    """Pointer of a feature-payload tensor, which must have the payload dtype of the call (float32 or bfloat16)."""
+    return dev_ptr(t, dtype)
+
+
+def payload_call(name, dtype, *args):
+    """`name` for float32 payloads, its `_bf16` twin for bfloat16 ones."""
+    if dtype == torch.float32:
+        return call(name, *args)
+    if dtype == torch.bfloat16 and name in BF16_TWINS:
+        return call(name + "_bf16", *args)
+    raise MgarError("%s: unsupported payload dtype %s" % (name, dtype))
 
 
 def iptr(t):
@@ -147,6 +170,7 @@ def kernel_timers(enable=None, reset=True):
     {kernel name: (total_ms, launches, algorithmic_bytes, flops)} since the last reset."""
     if enable is not None:
         call("mgar_ktimer_enable", int(bool(enable)))
+        _KT_STATE["on"] = bool(enable)
         return None
     _cdll.mgar_ktimer_name.restype = ctypes.c_char_p
     _cdll.mgar_ktimer_name.argtypes = [ctypes.c_int]
@@ -157,6 +181,24 @@ def kernel_timers(enable=None, reset=True):
         if n.value:
             out[_cdll.mgar_ktimer_name(i).decode()] = (ms.value, n.value, by.value, fl.value)
     return out
+
+
+_KT_IDS = {}
+
+
+_KT_STATE = {"on": False}
+
+
+def note_pair_tests(kernel, pairs):
+    """Instrumented runs only: credit `pairs` (query, point) distance evaluations (8 flop each) to `kernel`."""
+    if not _KT_STATE["on"]:
+        return
+    if not _KT_IDS:
+        _cdll.mgar_ktimer_name.restype = ctypes.c_char_p
+        _cdll.mgar_ktimer_name.argtypes = [ctypes.c_int]
+        for i in range(raw("mgar_ktimer_count")):
+            _KT_IDS[_cdll.mgar_ktimer_name(i).decode()] = i
+    call("mgar_ktimer_add_flops", _KT_IDS[kernel], float(pairs) * 8.0)
 
 
 def exported_symbols():

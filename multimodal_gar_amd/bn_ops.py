@@ -18,17 +18,27 @@ def _workspace(x, b, c, p):
     return torch.empty((L.raw("mgar_bn_workspace_floats", b, c, p),), dtype=torch.float32, device=x.device)
 
 
+_PAYLOADS = (torch.float32, torch.bfloat16)   # feature-payload dtypes of the kernels; statistics / affine are always fp32
+
+
+def _f32(t):
+    """BatchNorm vectors (affine, statistics) are fp32 whatever the payload type (a module converted with .to(bf16)
+    would otherwise hand bf16 vectors to kernels that read floats)."""
+    return t if t is None or t.dtype == torch.float32 else t.float()
+
+
 def _train_stats(x3, bn):
     b, c, p = x3.shape
     mean = torch.empty((c,), dtype=torch.float32, device=x3.device)
     invstd = torch.empty_like(mean)
     track = bn.track_running_stats and bn.running_mean is not None
     ws = _workspace(x3, b, c, p)
-    L.call("mgar_bn_train_stats", L.fptr(x3), b, c, p, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
-           L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
-           L.fptr(bn.running_var) if track else None,
-           L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
-           L.stream_of(x3))
+    L.payload_call("mgar_bn_train_stats", x3.dtype, L.pptr(x3, x3.dtype), b, c, p, float(bn.eps),
+                   float(bn.momentum if bn.momentum is not None else 0.1),
+                   L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
+                   L.fptr(bn.running_var) if track else None,
+                   L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
+                   L.stream_of(x3))
     return mean, invstd
 
 
@@ -39,8 +49,9 @@ class _BnAct(Function):
     def forward(ctx, x3, gamma, beta, mean, invstd, relu):
         b, c, p = x3.shape
         y = torch.empty_like(x3)
-        L.call("mgar_bn_act_fwd", L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), int(relu),
-               L.fptr(y), L.stream_of(x3))
+        dt = x3.dtype
+        L.payload_call("mgar_bn_act_fwd", dt, L.pptr(x3, dt), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+                       int(relu), L.pptr(y, dt), L.stream_of(x3))
         ctx.save_for_backward(x3, gamma, beta, mean, invstd)
         ctx.relu = bool(relu)
         return y
@@ -54,9 +65,10 @@ class _BnAct(Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         # every tensor whose pointer is passed stays bound to a name until the call returns: a
         # temporary freed mid-expression can be handed out again by the caching allocator
-        dy_c, ws = dy.contiguous(), _workspace(x3, b, c, p)
-        L.call("mgar_bn_act_bwd", L.fptr(dy_c), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
-               L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), L.stream_of(x3))
+        dt = x3.dtype
+        dy_c, ws = dy.contiguous().to(dt), _workspace(x3, b, c, p)
+        L.payload_call("mgar_bn_act_bwd", dt, L.pptr(dy_c, dt), L.pptr(x3, dt), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+                       L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.pptr(dx, dt), L.stream_of(x3))
         return dx, dgamma, dbeta, None, None, None
 
 
@@ -66,11 +78,13 @@ class _BnActMaxPool(Function):
     @staticmethod
     def forward(ctx, x4, gamma, beta, mean, invstd, relu):
         b, c, m, ns = x4.shape
-        out = torch.empty((b, c, m), dtype=torch.float32, device=x4.device)
+        dt = x4.dtype
+        out = torch.empty((b, c, m), dtype=dt, device=x4.device)
         arg = torch.empty((b, c, m), dtype=torch.uint8, device=x4.device)
-        xarg = torch.empty((b, c, m), dtype=torch.float32, device=x4.device) if x4.requires_grad or gamma.requires_grad else None
-        L.call("mgar_bn_act_maxpool_fwd", L.fptr(x4), b, c, m, ns, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
-               int(relu), L.fptr(out), _u8ptr(arg), L.fptr(xarg), L.stream_of(x4))
+        xarg = torch.empty((b, c, m), dtype=dt, device=x4.device) if x4.requires_grad or gamma.requires_grad else None
+        L.payload_call("mgar_bn_act_maxpool_fwd", dt, L.pptr(x4, dt), b, c, m, ns, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+                       L.fptr(beta), int(relu), L.pptr(out, dt), _u8ptr(arg), L.pptr(xarg, dt) if xarg is not None else None,
+                       L.stream_of(x4))
         ctx.save_for_backward(x4, gamma, mean, invstd, out, arg, xarg)
         ctx.relu = bool(relu)
         ctx.mark_non_differentiable(arg)
@@ -83,10 +97,11 @@ class _BnActMaxPool(Function):
         b, c, m, ns = x4.shape
         dx = torch.empty_like(x4)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        dpool_c, ws = dpool.contiguous(), _workspace(x4, b, c, m * ns)
-        L.call("mgar_bn_act_maxpool_bwd", L.fptr(dpool_c), L.fptr(out), _u8ptr(arg), L.fptr(x4), L.fptr(xarg), b, c, m, ns,
-               L.fptr(mean), L.fptr(invstd), L.fptr(gamma), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta),
-               L.fptr(dx), L.stream_of(x4))
+        dt = x4.dtype
+        dpool_c, ws = dpool.contiguous().to(dt), _workspace(x4, b, c, m * ns)
+        L.payload_call("mgar_bn_act_maxpool_bwd", dt, L.pptr(dpool_c, dt), L.pptr(out, dt), _u8ptr(arg), L.pptr(x4, dt),
+                       L.pptr(xarg, dt) if xarg is not None else None, b, c, m, ns, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
+                       int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.pptr(dx, dt), L.stream_of(x4))
         return dx, dgamma, dbeta, None, None, None
 
 
@@ -101,9 +116,10 @@ class _BnActConv(Function):
         b, c, p = x3.shape
         cout = w.shape[0]
         w = w.contiguous()
-        y = torch.empty((b, cout, p), dtype=torch.float32, device=x3.device)
-        L.call("mgar_pointwise_conv_fwd", L.fptr(x3), b, c, p, L.fptr(w), c, 1, cout, L.fptr(mean), L.fptr(invstd),
-               L.fptr(gamma), L.fptr(beta), int(relu), L.fptr(y), L.stream_of(x3))
+        dt = x3.dtype
+        y = torch.empty((b, cout, p), dtype=dt, device=x3.device)
+        L.payload_call("mgar_pointwise_conv_fwd", dt, L.pptr(x3, dt), b, c, p, L.fptr(w), c, 1, cout, L.fptr(mean), L.fptr(invstd),
+                       L.fptr(gamma), L.fptr(beta), int(relu), L.pptr(y, dt), L.stream_of(x3))
         ctx.save_for_backward(x3, gamma, beta, mean, invstd, w)
         ctx.relu = relu
         return y
@@ -141,8 +157,10 @@ FUSED_CONV_MAX_CHANNELS = 64   # csrc/pointwise_fwd.hip: Cout <= 64 in both dire
 def bn_act_conv(x, bn, relu, conv):
     """conv(relu?(bn(x))) for a bias-free kernel-size-1 ``conv`` in one fused step, or None if the
     shapes are outside the fused kernel (the caller then runs bn_act and the GEMM separately)."""
-    if not (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() >= 3 and conv.bias is None):
+    if not (x.is_cuda and x.dtype in _PAYLOADS and bn.training and x.dim() >= 3 and conv.bias is None):
         return None
+    if x.dtype != torch.float32 and torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return None   # the weight-gradient kernel (csrc/pointwise_dw.hip) takes fp32 payloads only: bf16 is a forward path
     c, cout = x.shape[1], conv.out_channels
     x3 = x.contiguous().flatten(2)
     if c > FUSED_CONV_MAX_CHANNELS or cout > FUSED_CONV_MAX_CHANNELS or x3.shape[2] % 4 != 0 \
@@ -150,20 +168,20 @@ def bn_act_conv(x, bn, relu, conv):
         return None
     mean, invstd = _stats(x3, bn)
     gamma, beta = _affine(bn, c, x.device)
-    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, conv.weight.view(cout, c))
+    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, _f32(conv.weight).view(cout, c))
     return y.view(x.shape[0], cout, *x.shape[2:])
 
 
 def _affine(bn, c, device):
     if bn.affine:
-        return bn.weight, bn.bias
+        return _f32(bn.weight), _f32(bn.bias)
     return torch.ones(c, device=device), torch.zeros(c, device=device)
 
 
 def _stats(x3, bn):
     if bn.training or not bn.track_running_stats:
         return _train_stats(x3, bn)
-    return bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+    return _f32(bn.running_mean), torch.rsqrt(_f32(bn.running_var) + bn.eps)
 
 
 def bn_act(x, bn, relu):
@@ -180,7 +198,7 @@ def bn_act_per_sample(x, bn, relu):
     """[relu](bn(x)) where every sample of x (G, C, ...) is normalised with its own batch statistics and the running
     statistics get the G momentum updates in sample order: G clips through a train-mode BatchNorm in ONE pass, with
     the result of feeding them one at a time.  Forward only (frozen I3D); None if that does not apply."""
-    if not (x.is_cuda and x.dtype == torch.float32 and bn.training and x.dim() >= 3) or (torch.is_grad_enabled() and
+    if not (x.is_cuda and x.dtype in _PAYLOADS and bn.training and x.dim() >= 3) or (torch.is_grad_enabled() and
                                                                                         (x.requires_grad or bn.weight.requires_grad)):
         return None
     x3 = x.contiguous().flatten(2)
@@ -192,14 +210,16 @@ def bn_act_per_sample(x, bn, relu):
     track = bn.track_running_stats and bn.running_mean is not None
     ws = _workspace(x3, 1, g * c, p)
     st = L.stream_of(x3)
-    L.call("mgar_bn_train_stats_grouped", L.fptr(x3), g, c, p, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
-           L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
-           L.fptr(bn.running_var) if track else None,
-           L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None, st)
+    dt = x3.dtype
+    L.payload_call("mgar_bn_train_stats_grouped", dt, L.pptr(x3, dt), g, c, p, float(bn.eps),
+                   float(bn.momentum if bn.momentum is not None else 0.1),
+                   L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
+                   L.fptr(bn.running_var) if track else None,
+                   L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None, st)
     gamma, beta = _affine(bn, c, x.device)
     y = torch.empty_like(x3)
-    L.call("mgar_bn_act_fwd_grouped", L.fptr(x3), g, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), int(relu),
-           L.fptr(y), st)
+    L.payload_call("mgar_bn_act_fwd_grouped", dt, L.pptr(x3, dt), g, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+                   int(relu), L.pptr(y, dt), st)
     return y.view(x.shape)
 
 

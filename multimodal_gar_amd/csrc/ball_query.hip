@@ -245,7 +245,7 @@ __global__ __launch_bounds__(BQ_THREADS) void ball_query_multi_kernel(int B, int
 template <bool STACK>
 static int bq_multi_launch(int B, int n, int m, int grid_x, int grid_y, int nr, const float *radii, const int *nsamples,
                            int *const *idx, const float *new_xyz, const int *new_cnt, const float *xyz, const int *xyz_cnt,
-                           double bytes, hipStream_t st, const char *what) {
+                           double bytes, double flops, hipStream_t st, const char *what) {
     BqMulti A;
     int rows = 0;
     for (int r = 0; r < BQ_MAX_RADII; ++r) {
@@ -259,7 +259,7 @@ static int bq_multi_launch(int B, int n, int m, int grid_x, int grid_y, int nr, 
         set_error("ball_query_multi: the nsample rows of all radii do not fit LDS");
         return MGAR_EUNSUPPORTED;
     }
-    KtScope kt(KT_BALL_QUERY, st, bytes);
+    KtScope kt(KT_BALL_QUERY, st, bytes, flops);
 #define BQM(NR)                                                                                                              \
     {                                                                                                                        \
         static bool attr_set = false;                                                                                        \
@@ -304,7 +304,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_ball_query_batch(int 
     MGAR_REQUIRE(b <= 65535, "ball_query_batch: b > 65535");
     const size_t lds = (size_t)(nsample * BQ_ROW_STRIDE + BQ_THREADS) * sizeof(int);
     dim3 grid(ceil_div(m, BQ_THREADS), b);
-    KtScope kt(KT_BALL_QUERY, (hipStream_t)stream, (double)b * (12.0 * n + 12.0 * m + 4.0 * m * nsample));
+    KtScope kt(KT_BALL_QUERY, (hipStream_t)stream, (double)b * (12.0 * n + 12.0 * m + 4.0 * m * nsample), 8.0 * b * (double)m * n);   // <= m*n pair tests of 8 flop
     hipLaunchKernelGGL(ball_query_kernel<false>, grid, dim3(BQ_THREADS), lds, (hipStream_t)stream, b, n, m,
                        radius * radius, nsample, new_xyz, (const int *)nullptr, xyz, (const int *)nullptr, idx);
     return check_launch("ball_query_batch: launch failed");
@@ -342,7 +342,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_ball_query_multi_batc
     MGAR_REQUIRE(b <= 65535, "ball_query_multi_batch: b > 65535");
     double bytes = (double)b * (12.0 * n + 12.0 * m);
     for (int r = 0; r < nr; ++r) bytes += 4.0 * b * m * nsamples[r];
-    return bq_multi_launch<false>(b, n, m, ceil_div(m, BQ_THREADS), b, nr, radii, nsamples, idx, new_xyz, nullptr, xyz, nullptr, bytes,
+    return bq_multi_launch<false>(b, n, m, ceil_div(m, BQ_THREADS), b, nr, radii, nsamples, idx, new_xyz, nullptr, xyz, nullptr, bytes, 8.0 * b * (double)m * n,
                                   (hipStream_t)stream, "ball_query_multi_batch: launch failed");
 }
 
@@ -361,5 +361,5 @@ extern "C" __attribute__((visibility("default"))) int mgar_ball_query_multi_stac
     double bytes = 12.0 * M;
     for (int r = 0; r < nr; ++r) bytes += 4.0 * M * nsamples[r];
     return bq_multi_launch<true>(B, 0, 0, ceil_div(M, BQ_THREADS) + B, 1, nr, radii, nsamples, idx, new_xyz, new_xyz_batch_cnt, xyz,
-                                 xyz_batch_cnt, bytes, (hipStream_t)stream, "ball_query_multi_stack: launch failed");
+                                 xyz_batch_cnt, bytes, 0.0, (hipStream_t)stream, "ball_query_multi_stack: launch failed");
 }

@@ -20,6 +20,7 @@
 //     max-pool the reduction touches only the arg-max elements.
 // All kernels are HBM-bound streaming passes: bytes per element are listed at each kernel.
 #include "common.hpp"
+#include "payload.hpp"
 
 namespace mgar {
 
@@ -50,7 +51,8 @@ __device__ __forceinline__ size_t chan_off(long long e, int c, int C, int P) {
 // partial[(c * nchunk + chunk) * 2 + {0,1}] = chunk mean, chunk M2 = sum (x - chunk mean)^2; bn_finalize_kernel merges
 // the chunks with Chan's parallel formula in double.  (With |mean| >> std a plain sum / sum-of-squares loses the
 // variance digits already in the fp32 partials: ADVICE r1.)
-__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__restrict__ x, int B, int C, int P, int chunk,
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const T *__restrict__ x, int B, int C, int P, int chunk,
                                                                 float *__restrict__ partial) {
     __shared__ float scratch[BN_THREADS / 64];
     const int c = blockIdx.y;
@@ -58,20 +60,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const float *__r
     const long long e0 = (long long)blockIdx.x * chunk;
     const long long e1 = min(e0 + chunk, n);
     const long long npiv = min((long long)BN_THREADS, e1 - e0);
-    float pv = threadIdx.x < npiv ? x[chan_off(e0 + threadIdx.x, c, C, P)] : 0.f;
+    float pv = threadIdx.x < npiv ? Payload<T>::ld(x + chan_off(e0 + threadIdx.x, c, C, P)) : 0.f;
     const float pivot = block_sum(pv, scratch) / (float)npiv;
     float s = 0.f, q = 0.f;
     if ((P & 3) == 0) {
 #pragma unroll 4
         for (long long e = e0 + (long long)threadIdx.x * 4; e < e1; e += BN_THREADS * 4) {
-            float4 v = *reinterpret_cast<const float4 *>(x + chan_off(e, c, C, P));
+            float4 v = Payload<T>::ld4(x + chan_off(e, c, C, P));
             v.x -= pivot; v.y -= pivot; v.z -= pivot; v.w -= pivot;
             s += (v.x + v.y) + (v.z + v.w);
             q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
     } else {
         for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
-            const float v = x[chan_off(e, c, C, P)] - pivot;
+            const float v = Payload<T>::ld(x + chan_off(e, c, C, P)) - pivot;
             s += v;
             q += v * v;
         }
@@ -127,11 +129,11 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict
 // grid (B*C rows, ceil(P / (256*4*BN_APPLY_V)))
 constexpr int BN_APPLY_V = 4;  // float4 per thread
 
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__restrict__ x, int C, int P,
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restrict__ x, int C, int P,
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                              float *__restrict__ y, int stats_per_row) {
+                                                              T *__restrict__ y, int stats_per_row) {
     const int row = blockIdx.x;
     const int c = row % C;
     const int sidx = stats_per_row ? row : c;   // per-sample statistics: mean / invstd have one entry per (sample, channel)
@@ -139,24 +141,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
     // magnitude of mean * sc (x - mean is exact for x within a factor 2 of mean)
     const float sc = invstd[sidx] * (gamma ? gamma[c] : 1.f);
     const float mu = mean[sidx], sh = beta ? beta[c] : 0.f;
-    const float *xr = x + (size_t)row * P;
-    float *yr = y + (size_t)row * P;
+    const T *xr = x + (size_t)row * P;
+    T *yr = y + (size_t)row * P;
     const int base = blockIdx.y * (BN_THREADS * 4 * BN_APPLY_V);
     if ((P & 3) == 0) {
 #pragma unroll
         for (int u = 0; u < BN_APPLY_V; ++u) {
             const int p = base + (u * BN_THREADS + threadIdx.x) * 4;
             if (p < P) {
-                float4 v = *reinterpret_cast<const float4 *>(xr + p);
+                float4 v = Payload<T>::ld4(xr + p);
                 v.x = (v.x - mu) * sc + sh; v.y = (v.y - mu) * sc + sh; v.z = (v.z - mu) * sc + sh; v.w = (v.w - mu) * sc + sh;
                 if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4 *>(yr + p) = v;
+                Payload<T>::st4(yr + p, v);
             }
         }
     } else {
         for (int p = base + threadIdx.x; p < min(P, base + BN_THREADS * 4 * BN_APPLY_V); p += BN_THREADS) {
-            float v = (xr[p] - mu) * sc + sh;
-            yr[p] = RELU ? fmaxf(v, 0.f) : v;
+            float v = (Payload<T>::ld(xr + p) - mu) * sc + sh;
+            Payload<T>::st(yr + p, RELU ? fmaxf(v, 0.f) : v);
         }
     }
 }
@@ -179,24 +181,24 @@ __device__ __forceinline__ void dpp_max_step(float &v, int &i) {
 
 constexpr int BN_MAX_V = 4;   // float4 per thread: four independent 16-byte loads in flight
 
-template <bool RELU, int G>   // G = NS / 4 lanes per group: 1, 2, 4, 8 or 16
-__global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__restrict__ x, int C, int M, int NS,
+template <bool RELU, int G, typename T>   // G = NS / 4 lanes per group: 1, 2, 4, 8 or 16
+__global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const T *__restrict__ x, int C, int M, int NS,
                                                                 const float *__restrict__ mean, const float *__restrict__ invstd,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                                float *__restrict__ out, unsigned char *__restrict__ arg,
-                                                                float *__restrict__ xarg) {
+                                                                T *__restrict__ out, unsigned char *__restrict__ arg,
+                                                                T *__restrict__ xarg) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
     const float mu = mean[c], sh = beta ? beta[c] : 0.f;
     const long long nq = (long long)M * G;
-    const float *xr = x + (size_t)row * M * NS;
+    const T *xr = x + (size_t)row * M * NS;
     float4 v[BN_MAX_V];
     long long qs[BN_MAX_V];
 #pragma unroll
     for (int u = 0; u < BN_MAX_V; ++u) {   // float4 index inside the row; whole groups are live or dead together
         qs[u] = ((long long)blockIdx.y * BN_MAX_V + u) * BN_THREADS + threadIdx.x;
-        v[u] = qs[u] < nq ? *reinterpret_cast<const float4 *>(xr + qs[u] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[u] = qs[u] < nq ? Payload<T>::ld4(xr + qs[u] * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < BN_MAX_V; ++u) {
@@ -217,44 +219,44 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_vec_kernel(const float *__r
         if (G >= 16) dpp_max_step<0x140>(best, bi);  // row_mirror           (acts as xor 8)
         if (live && (threadIdx.x & (G - 1)) == 0) {
             const long long m = q / G;
-            out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
+            Payload<T>::st(out + (size_t)row * M + m, RELU ? fmaxf(best, 0.f) : best);
             arg[(size_t)row * M + m] = (unsigned char)bi;
             // the pre-BN value at the arg-max (the line was just read: an L1/L2 hit), so that the backward
             // reduction reads three coalesced (B,C,M) arrays instead of gathering one element per group
-            if (xarg) xarg[(size_t)row * M + m] = xr[m * NS + bi];
+            if (xarg) xarg[(size_t)row * M + m] = xr[m * NS + bi];   // a copy: no conversion
         }
     }
 }
 
 // generic fallback (NS not in {4, 8, 16, 32, 64}): one thread per group.  grid (rows, ceil(M/256))
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const float *__restrict__ x, int C, int M, int NS,
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_kernel(const T *__restrict__ x, int C, int M, int NS,
                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
                                                             const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                            float *__restrict__ out, unsigned char *__restrict__ arg,
-                                                            float *__restrict__ xarg) {
+                                                            T *__restrict__ out, unsigned char *__restrict__ arg,
+                                                            T *__restrict__ xarg) {
     const int row = blockIdx.x;
     const int m = blockIdx.y * BN_THREADS + threadIdx.x;
     if (m >= M) return;
     const int c = row % C;
     const float sc = invstd[c] * (gamma ? gamma[c] : 1.f);
     const float mu = mean[c], sh = beta ? beta[c] : 0.f;
-    const float *xr = x + ((size_t)row * M + m) * NS;
+    const T *xr = x + ((size_t)row * M + m) * NS;
     float best = -__builtin_inff();
     int bi = 0;
     for (int s = 0; s < NS; ++s) {
-        const float a = (xr[s] - mu) * sc + sh;
+        const float a = (Payload<T>::ld(xr + s) - mu) * sc + sh;
         if (a > best) { best = a; bi = s; }
     }
-    out[(size_t)row * M + m] = RELU ? fmaxf(best, 0.f) : best;
+    Payload<T>::st(out + (size_t)row * M + m, RELU ? fmaxf(best, 0.f) : best);
     arg[(size_t)row * M + m] = (unsigned char)bi;
     if (xarg) xarg[(size_t)row * M + m] = xr[bi];
 }
 
 // ---- backward reduction: 8 B read per element ---------------------------------------------------
 // partial[(c*nchunk + chunk)*2 + {0,1}] = sum dz, sum dz * xhat    with dz = dy * [relu active]
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T *__restrict__ dy, const T *__restrict__ x,
                                                                     int B, int C, int P, const float *__restrict__ mean,
                                                                     const float *__restrict__ invstd,
                                                                     const float *__restrict__ gamma,
@@ -277,14 +279,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
     if ((P & 3) == 0) {
         for (long long e = e0 + (long long)threadIdx.x * 4; e < e1; e += BN_THREADS * 4) {
             const size_t o = chan_off(e, c, C, P);
-            const float4 xv = *reinterpret_cast<const float4 *>(x + o);
-            const float4 dv = *reinterpret_cast<const float4 *>(dy + o);
+            const float4 xv = Payload<T>::ld4(x + o);
+            const float4 dv = Payload<T>::ld4(dy + o);
             acc(xv.x, dv.x); acc(xv.y, dv.y); acc(xv.z, dv.z); acc(xv.w, dv.w);
         }
     } else {
         for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
             const size_t o = chan_off(e, c, C, P);
-            acc(x[o], dy[o]);
+            acc(Payload<T>::ld(x + o), Payload<T>::ld(dy + o));
         }
     }
     s = block_sum(s, scratch);
@@ -297,12 +299,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
 
 // after a fused max-pool only the arg-max element of every group carries gradient:
 // 13 B read per GROUP.  grid (nchunk over B*M, C)
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const float *__restrict__ dpool,
-                                                                        const float *__restrict__ pooled,
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const T *__restrict__ dpool,
+                                                                        const T *__restrict__ pooled,
                                                                         const unsigned char *__restrict__ arg,
-                                                                        const float *__restrict__ x,
-                                                                        const float *__restrict__ xarg, int B, int C, int M, int NS,
+                                                                        const T *__restrict__ x,
+                                                                        const T *__restrict__ xarg, int B, int C, int M, int NS,
                                                                         const float *__restrict__ mean,
                                                                         const float *__restrict__ invstd,
                                                                         float *__restrict__ partial) {
@@ -315,9 +317,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const fl
     float s = 0.f, q = 0.f;
     for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
         const size_t o = chan_off(e, c, C, M);
-        float d = dpool[o];
-        if (RELU && !(pooled[o] > 0.f)) d = 0.f;
-        const float xh = ((xarg ? xarg[o] : x[o * NS + arg[o]]) - mu) * is;
+        float d = Payload<T>::ld(dpool + o);
+        if (RELU && !(Payload<T>::ld(pooled + o) > 0.f)) d = 0.f;
+        const float xh = ((xarg ? Payload<T>::ld(xarg + o) : Payload<T>::ld(x + o * NS + arg[o])) - mu) * is;
         s += d;
         q += d * xh;
     }
@@ -350,12 +352,12 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float *__rest
 
 // ---- backward apply: dx = gamma*invstd * (dz - mean(dz) - xhat * mean(dz*xhat)) ----------------
 // 8 B read + 4 B written per element.  grid (ceil(P/(256*4)), B*C)
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, int C,
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T *__restrict__ dy, const T *__restrict__ x, int C,
                                                                   int P, const float *__restrict__ mean,
                                                                   const float *__restrict__ invstd, const float *__restrict__ gamma,
                                                                   const float *__restrict__ beta, const float *__restrict__ coef,
-                                                                  float *__restrict__ dx) {
+                                                                  T *__restrict__ dx) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float mu = mean[c], is = invstd[c];
@@ -371,28 +373,28 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
     if ((P & 3) == 0) {
         const int p0 = (blockIdx.y * BN_THREADS + threadIdx.x) * 4;
         if (p0 >= P) return;
-        const float4 xv = *reinterpret_cast<const float4 *>(x + ro + p0);
-        const float4 dv = *reinterpret_cast<const float4 *>(dy + ro + p0);
+        const float4 xv = Payload<T>::ld4(x + ro + p0);
+        const float4 dv = Payload<T>::ld4(dy + ro + p0);
         float4 r;
         r.x = one(xv.x, dv.x); r.y = one(xv.y, dv.y); r.z = one(xv.z, dv.z); r.w = one(xv.w, dv.w);
-        *reinterpret_cast<float4 *>(dx + ro + p0) = r;
+        Payload<T>::st4(dx + ro + p0, r);
     } else {
         const int p0 = blockIdx.y * BN_THREADS + threadIdx.x;
-        if (p0 < P) dx[ro + p0] = one(x[ro + p0], dy[ro + p0]);
+        if (p0 < P) Payload<T>::st(dx + ro + p0, one(Payload<T>::ld(x + ro + p0), Payload<T>::ld(dy + ro + p0)));
     }
 }
 
 // after a fused max-pool: 4 B read + 4 B written per element (+ 9 B per group, cached).
 // lanes run along the flat (m, s) index, 4 elements per lane.  grid (ceil(M*NS/(256*4)), B*C)
-template <bool RELU>
-__global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const float *__restrict__ dpool,
-                                                                      const float *__restrict__ pooled,
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const T *__restrict__ dpool,
+                                                                      const T *__restrict__ pooled,
                                                                       const unsigned char *__restrict__ arg,
-                                                                      const float *__restrict__ x, int C, int M, int NS,
+                                                                      const T *__restrict__ x, int C, int M, int NS,
                                                                       const float *__restrict__ mean,
                                                                       const float *__restrict__ invstd,
                                                                       const float *__restrict__ gamma,
-                                                                      const float *__restrict__ coef, float *__restrict__ dx) {
+                                                                      const float *__restrict__ coef, T *__restrict__ dx) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float mu = mean[c], is = invstd[c];
@@ -405,19 +407,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const floa
     const long long p0 = ((long long)blockIdx.y * BN_THREADS + threadIdx.x) * step;
     if (p0 >= P) return;
     const int m = (int)(p0 / NS), s0 = (int)(p0 - (long long)m * NS);
-    float d = dpool[go + m];
-    if (RELU && !(pooled[go + m] > 0.f)) d = 0.f;
+    float d = Payload<T>::ld(dpool + go + m);
+    if (RELU && !(Payload<T>::ld(pooled + go + m) > 0.f)) d = 0.f;
     const int a = arg[go + m];
     if (step == 4) {
-        const float4 xv = *reinterpret_cast<const float4 *>(x + ro + p0);
+        const float4 xv = Payload<T>::ld4(x + ro + p0);
         float4 r;
         r.x = k * ((s0 + 0 == a ? d : 0.f) - m0 - (xv.x - mu) * is * m1);
         r.y = k * ((s0 + 1 == a ? d : 0.f) - m0 - (xv.y - mu) * is * m1);
         r.z = k * ((s0 + 2 == a ? d : 0.f) - m0 - (xv.z - mu) * is * m1);
         r.w = k * ((s0 + 3 == a ? d : 0.f) - m0 - (xv.w - mu) * is * m1);
-        *reinterpret_cast<float4 *>(dx + ro + p0) = r;
+        Payload<T>::st4(dx + ro + p0, r);
     } else {
-        dx[ro + p0] = k * ((s0 == a ? d : 0.f) - m0 - (x[ro + p0] - mu) * is * m1);
+        Payload<T>::st(dx + ro + p0, k * ((s0 == a ? d : 0.f) - m0 - (Payload<T>::ld(x + ro + p0) - mu) * is * m1));
     }
 }
 
@@ -449,7 +451,10 @@ BN_API int mgar_bn_workspace_floats(int B, int C, int P) {
 
 static int bn_sizes_ok(int B, int C, long long P) { return B >= 0 && C >= 0 && P >= 0 && (long long)B * C <= 2147483647LL; }
 
-BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean,
+// ---- implementations, templated on the payload type (float / bf16_t); statistics, affine and gradients of the affine
+// are always fp32 ----
+template <typename T>
+static int bn_train_stats_impl(const T *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean,
                                float *invstd, float *running_mean, float *running_var, long long *num_batches_tracked,
                                void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_train_stats: bad sizes");
@@ -458,25 +463,26 @@ BN_API int mgar_bn_train_stats(const float *x, int B, int C, int P, float eps, f
     MGAR_REQUIRE(C <= 65535, "bn_train_stats: C > 65535");
     const int chunk = bn_chunk(B, C, P), nchunk = bn_nchunk_fwd(B, C, P);
     hipStream_t st = (hipStream_t)stream;
-    { KtScope kt(KT_BN_STATS, st, 4.0 * (double)B * C * P);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, chunk, workspace);
+    { KtScope kt(KT_BN_STATS, st, (double)sizeof(T) * B * C * P);
+    hipLaunchKernelGGL(bn_partial_kernel<T>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, x, B, C, P, chunk, workspace);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, chunk, eps,
                        momentum, mean, invstd, running_mean, running_var, num_batches_tracked, (float *)nullptr);
     return check_launch("bn_train_stats: launch failed");
 }
 
-BN_API int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
-                           const float *beta, int relu, float *y, void *stream) {
+template <typename T>
+static int bn_act_fwd_impl(const T *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
+                           const float *beta, int relu, T *y, int stats_per_row, void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_fwd: bad sizes");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(x && y && mean && invstd, "bn_act_fwd: null pointer");
     MGAR_REQUIRE((long long)P <= 65535LL * BN_THREADS * 4, "bn_act_fwd: P too large");
     dim3 grid(B * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
     hipStream_t st = (hipStream_t)stream;
-    { KtScope kt(KT_BN_APPLY, st, 8.0 * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 0);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 0);
+    { KtScope kt(KT_BN_APPLY, st, 2.0 * sizeof(T) * (double)B * C * P);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, stats_per_row);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, stats_per_row);
     }
     return check_launch("bn_act_fwd: launch failed");
 }
@@ -501,7 +507,8 @@ __global__ void bn_running_update_grouped_kernel(const float *__restrict__ mean,
     if (running_var) running_var[c] = rv;
 }
 
-BN_API int mgar_bn_train_stats_grouped(const float *x, int G, int C, int P, float eps, float momentum, float *workspace,
+template <typename T>
+static int bn_train_stats_grouped_impl(const T *x, int G, int C, int P, float eps, float momentum, float *workspace,
                                        float *mean, float *invstd, float *running_mean, float *running_var,
                                        long long *num_batches_tracked, void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(G, C, P), "bn_train_stats_grouped: bad sizes");
@@ -512,8 +519,8 @@ BN_API int mgar_bn_train_stats_grouped(const float *x, int G, int C, int P, floa
     const int chunk = bn_chunk(1, rows, P), nchunk = bn_nchunk_fwd(1, rows, P);
     hipStream_t st = (hipStream_t)stream;
     float *var = workspace + (size_t)2 * rows * nchunk;   // biased variances, rows floats (inside mgar_bn_workspace_floats(1, G*C, P))
-    { KtScope kt(KT_BN_STATS, st, 4.0 * (double)G * C * P);
-    hipLaunchKernelGGL(bn_partial_kernel, dim3(nchunk, rows), dim3(BN_THREADS), 0, st, x, 1, rows, P, chunk, workspace);
+    { KtScope kt(KT_BN_STATS, st, (double)sizeof(T) * G * C * P);
+    hipLaunchKernelGGL(bn_partial_kernel<T>, dim3(nchunk, rows), dim3(BN_THREADS), 0, st, x, 1, rows, P, chunk, workspace);
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(rows), dim3(64), 0, st, workspace, nchunk, rows, (double)P, chunk, eps, momentum, mean,
                        invstd, (float *)nullptr, (float *)nullptr, (long long *)nullptr, var);
@@ -523,34 +530,21 @@ BN_API int mgar_bn_train_stats_grouped(const float *x, int G, int C, int P, floa
     return check_launch("bn_train_stats_grouped: launch failed");
 }
 
-BN_API int mgar_bn_act_fwd_grouped(const float *x, int G, int C, int P, const float *mean, const float *invstd, const float *gamma,
-                                   const float *beta, int relu, float *y, void *stream) {
-    MGAR_REQUIRE(bn_sizes_ok(G, C, P), "bn_act_fwd_grouped: bad sizes");
-    if ((long long)G * C * P == 0) return MGAR_OK;
-    MGAR_REQUIRE(x && y && mean && invstd, "bn_act_fwd_grouped: null pointer");
-    MGAR_REQUIRE((long long)P <= 65535LL * BN_THREADS * 4, "bn_act_fwd_grouped: P too large");
-    dim3 grid(G * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
-    hipStream_t st = (hipStream_t)stream;
-    KtScope kt(KT_BN_APPLY, st, 8.0 * (double)G * C * P);
-    if (relu) hipLaunchKernelGGL(bn_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 1);
-    else hipLaunchKernelGGL(bn_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, 1);
-    return check_launch("bn_act_fwd_grouped: launch failed");
-}
-
-BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean, const float *invstd,
-                                   const float *gamma, const float *beta, int relu, float *out, unsigned char *arg,
-                                   float *xarg, void *stream) {
+template <typename T>
+static int bn_act_maxpool_fwd_impl(const T *x, int B, int C, int M, int nsample, const float *mean, const float *invstd,
+                                   const float *gamma, const float *beta, int relu, T *out, unsigned char *arg,
+                                   T *xarg, void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_fwd: bad sizes");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(x && out && arg && mean && invstd, "bn_act_maxpool_fwd: null pointer");
     MGAR_REQUIRE((long long)M <= 65535LL * BN_THREADS, "bn_act_maxpool_fwd: M too large");
     hipStream_t st = (hipStream_t)stream;
-    KtScope kt(KT_BN_MAX, st, (double)B * C * M * (4.0 * nsample + 5.0));
+    KtScope kt(KT_BN_MAX, st, (double)B * C * M * ((double)sizeof(T) * nsample + sizeof(T) + 1.0));
 #define BN_MAX_VEC(G)                                                                                                  \
     {                                                                                                                  \
         dim3 gv(B * C, ceil_div((long long)M * (G), BN_THREADS * BN_MAX_V));                                                      \
-        if (relu) hipLaunchKernelGGL((bn_max_vec_kernel<true, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg); \
-        else hipLaunchKernelGGL((bn_max_vec_kernel<false, G>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);     \
+        if (relu) hipLaunchKernelGGL((bn_max_vec_kernel<true, G, T>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg); \
+        else hipLaunchKernelGGL((bn_max_vec_kernel<false, G, T>), gv, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);     \
     }
     if (nsample == 4) BN_MAX_VEC(1)
     else if (nsample == 8) BN_MAX_VEC(2)
@@ -559,16 +553,17 @@ BN_API int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsam
     else if (nsample == 64) BN_MAX_VEC(16)
     else {
         dim3 grid(B * C, ceil_div(M, BN_THREADS));
-        if (relu) hipLaunchKernelGGL(bn_max_kernel<true>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);
-        else hipLaunchKernelGGL(bn_max_kernel<false>, grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);
+        if (relu) hipLaunchKernelGGL((bn_max_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);
+        else hipLaunchKernelGGL((bn_max_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, x, C, M, nsample, mean, invstd, gamma, beta, out, arg, xarg);
     }
 #undef BN_MAX_VEC
     return check_launch("bn_act_maxpool_fwd: launch failed");
 }
 
-BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+template <typename T>
+static int bn_act_bwd_impl(const T *dy, const T *x, int B, int C, int P, const float *mean, const float *invstd,
                            const float *gamma, const float *beta, int relu, float *workspace, float *dgamma, float *dbeta,
-                           float *dx, void *stream) {
+                           T *dx, void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_bwd: bad sizes");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx, "bn_act_bwd: null pointer");
@@ -576,22 +571,24 @@ BN_API int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P,
     const int nchunk = bn_nchunk(B, P);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
-    { KtScope kt(KT_BN_BWD_REDUCE, st, 8.0 * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL(bn_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
-    else hipLaunchKernelGGL(bn_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    { KtScope kt(KT_BN_BWD_REDUCE, st, 2.0 * sizeof(T) * (double)B * C * P);
+    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
-    { KtScope kt(KT_BN_BWD_APPLY, st, 12.0 * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    { KtScope kt(KT_BN_BWD_APPLY, st, 3.0 * sizeof(T) * (double)B * C * P);
+    if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
     }
     return check_launch("bn_act_bwd: launch failed");
 }
 
-BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x,
-                                   const float *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
-                                   float *workspace, float *dgamma, float *dbeta, float *dx, void *stream) {
+template <typename T>
+static int bn_act_maxpool_bwd_impl(const T *dpool, const T *pooled, const unsigned char *arg, const T *x,
+                                   const T *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd,
+                                   const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta, T *dx,
+                                   void *stream) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_bwd: bad sizes");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(dpool && pooled && arg && x && mean && invstd && workspace && dx, "bn_act_maxpool_bwd: null pointer");
@@ -599,16 +596,76 @@ BN_API int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, cons
     const int nchunk = bn_nchunk(B, M);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
-    { KtScope kt(KT_BN_MAX_BWD_REDUCE, st, 13.0 * (double)B * C * M);
-    if (relu) hipLaunchKernelGGL(bn_max_bwd_partial_kernel<true>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
-    else hipLaunchKernelGGL(bn_max_bwd_partial_kernel<false>, dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
+    { KtScope kt(KT_BN_MAX_BWD_REDUCE, st, (3.0 * sizeof(T) + 1.0) * (double)B * C * M);
+    if (relu) hipLaunchKernelGGL((bn_max_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
+    else hipLaunchKernelGGL((bn_max_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
     }
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)));
-    { KtScope kt(KT_BN_MAX_BWD_APPLY, st, (double)B * C * M * (8.0 * nsample + 9.0));
-    if (relu) hipLaunchKernelGGL(bn_max_bwd_apply_kernel<true>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
-    else hipLaunchKernelGGL(bn_max_bwd_apply_kernel<false>, grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
+    { KtScope kt(KT_BN_MAX_BWD_APPLY, st, (double)B * C * M * (2.0 * sizeof(T) * nsample + 2.0 * sizeof(T) + 1.0));
+    if (relu) hipLaunchKernelGGL((bn_max_bwd_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
+    else hipLaunchKernelGGL((bn_max_bwd_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
     }
     return check_launch("bn_act_maxpool_bwd: launch failed");
 }
+
+// ---- C ABI: fp32 payload (include/mgar_ops.h) and the bf16-payload twins (suffix _bf16; same arguments, the payload
+// pointers -- x, y, out, xarg, dy, dx, dpool, pooled -- address bf16 elements) ----
+#define BN_BOTH(NAME, PARAMS_F, PARAMS_B, CALL_F, CALL_B)      \
+    BN_API int NAME PARAMS_F { return CALL_F; }                  \
+    BN_API int NAME##_bf16 PARAMS_B { return CALL_B; }
+typedef const bf16_t *cbf;
+typedef bf16_t *mbf;
+
+BN_BOTH(mgar_bn_train_stats,
+        (const float *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean, float *invstd,
+         float *running_mean, float *running_var, long long *num_batches_tracked, void *stream),
+        (const void *x, int B, int C, int P, float eps, float momentum, float *workspace, float *mean, float *invstd,
+         float *running_mean, float *running_var, long long *num_batches_tracked, void *stream),
+        bn_train_stats_impl<float>(x, B, C, P, eps, momentum, workspace, mean, invstd, running_mean, running_var, num_batches_tracked, stream),
+        bn_train_stats_impl<bf16_t>((cbf)x, B, C, P, eps, momentum, workspace, mean, invstd, running_mean, running_var, num_batches_tracked, stream))
+BN_BOTH(mgar_bn_train_stats_grouped,
+        (const float *x, int G, int C, int P, float eps, float momentum, float *workspace, float *mean, float *invstd,
+         float *running_mean, float *running_var, long long *num_batches_tracked, void *stream),
+        (const void *x, int G, int C, int P, float eps, float momentum, float *workspace, float *mean, float *invstd,
+         float *running_mean, float *running_var, long long *num_batches_tracked, void *stream),
+        bn_train_stats_grouped_impl<float>(x, G, C, P, eps, momentum, workspace, mean, invstd, running_mean, running_var, num_batches_tracked, stream),
+        bn_train_stats_grouped_impl<bf16_t>((cbf)x, G, C, P, eps, momentum, workspace, mean, invstd, running_mean, running_var, num_batches_tracked, stream))
+BN_BOTH(mgar_bn_act_fwd,
+        (const float *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma, const float *beta,
+         int relu, float *y, void *stream),
+        (const void *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma, const float *beta,
+         int relu, void *y, void *stream),
+        bn_act_fwd_impl<float>(x, B, C, P, mean, invstd, gamma, beta, relu, y, 0, stream),
+        bn_act_fwd_impl<bf16_t>((cbf)x, B, C, P, mean, invstd, gamma, beta, relu, (mbf)y, 0, stream))
+BN_BOTH(mgar_bn_act_fwd_grouped,
+        (const float *x, int G, int C, int P, const float *mean, const float *invstd, const float *gamma, const float *beta,
+         int relu, float *y, void *stream),
+        (const void *x, int G, int C, int P, const float *mean, const float *invstd, const float *gamma, const float *beta,
+         int relu, void *y, void *stream),
+        bn_act_fwd_impl<float>(x, G, C, P, mean, invstd, gamma, beta, relu, y, 1, stream),
+        bn_act_fwd_impl<bf16_t>((cbf)x, G, C, P, mean, invstd, gamma, beta, relu, (mbf)y, 1, stream))
+BN_BOTH(mgar_bn_act_maxpool_fwd,
+        (const float *x, int B, int C, int M, int nsample, const float *mean, const float *invstd, const float *gamma,
+         const float *beta, int relu, float *out, unsigned char *arg, float *xarg, void *stream),
+        (const void *x, int B, int C, int M, int nsample, const float *mean, const float *invstd, const float *gamma,
+         const float *beta, int relu, void *out, unsigned char *arg, void *xarg, void *stream),
+        bn_act_maxpool_fwd_impl<float>(x, B, C, M, nsample, mean, invstd, gamma, beta, relu, out, arg, xarg, stream),
+        bn_act_maxpool_fwd_impl<bf16_t>((cbf)x, B, C, M, nsample, mean, invstd, gamma, beta, relu, (mbf)out, arg, (mbf)xarg, stream))
+BN_BOTH(mgar_bn_act_bwd,
+        (const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
+         const float *beta, int relu, float *workspace, float *dgamma, float *dbeta, float *dx, void *stream),
+        (const void *dy, const void *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
+         const float *beta, int relu, float *workspace, float *dgamma, float *dbeta, void *dx, void *stream),
+        bn_act_bwd_impl<float>(dy, x, B, C, P, mean, invstd, gamma, beta, relu, workspace, dgamma, dbeta, dx, stream),
+        bn_act_bwd_impl<bf16_t>((cbf)dy, (cbf)x, B, C, P, mean, invstd, gamma, beta, relu, workspace, dgamma, dbeta, (mbf)dx, stream))
+BN_BOTH(mgar_bn_act_maxpool_bwd,
+        (const float *dpool, const float *pooled, const unsigned char *arg, const float *x, const float *xarg, int B, int C,
+         int M, int nsample, const float *mean, const float *invstd, const float *gamma, int relu, float *workspace,
+         float *dgamma, float *dbeta, float *dx, void *stream),
+        (const void *dpool, const void *pooled, const unsigned char *arg, const void *x, const void *xarg, int B, int C,
+         int M, int nsample, const float *mean, const float *invstd, const float *gamma, int relu, float *workspace,
+         float *dgamma, float *dbeta, void *dx, void *stream),
+        bn_act_maxpool_bwd_impl<float>(dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, gamma, relu, workspace, dgamma, dbeta, dx, stream),
+        bn_act_maxpool_bwd_impl<bf16_t>((cbf)dpool, (cbf)pooled, arg, (cbf)x, (cbf)xarg, B, C, M, nsample, mean, invstd, gamma, relu, workspace, dgamma, dbeta, (mbf)dx, stream))

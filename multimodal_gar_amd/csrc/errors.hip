@@ -50,7 +50,7 @@ void kt_end(int id, hipStream_t st, double bytes, double flops) {
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 2; }
+extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 3; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_last_error(void) { return mgar::g_last_error; }
 
 extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on) {
@@ -60,6 +60,15 @@ extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on)
 extern "C" __attribute__((visibility("default"))) int mgar_ktimer_count(void) { return KT_COUNT; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_ktimer_name(int id) {
     return id >= 0 && id < KT_COUNT ? kKtNames[id] : "";
+}
+// Adds flops to kernel `id`'s total: for launches whose work the library cannot know (stacked layouts keep their
+// per-sample counts on the device), the instrumenting caller supplies it.
+extern "C" __attribute__((visibility("default"))) int mgar_ktimer_add_flops(int id, double flops) {
+    MGAR_REQUIRE(id >= 0 && id < KT_COUNT, "ktimer_add_flops: bad kernel id");
+    if (!g_kt_on) return MGAR_OK;
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    g_kt[id].flops += flops;
+    return MGAR_OK;
 }
 // Waits for the recorded events of kernel `id`, adds their elapsed times, returns the totals since the
 // last reset (reset != 0 clears them afterwards).

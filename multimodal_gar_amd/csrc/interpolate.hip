@@ -15,6 +15,7 @@
 // Stack layout (M,C): lanes run along c so every access is a contiguous feature row;
 // the backward's float atomics therefore cover whole row segments.
 #include "common.hpp"
+#include "payload.hpp"
 
 namespace mgar {
 
@@ -114,25 +115,27 @@ constexpr int TI_LDS_MAX_FLOATS = 36864;   // 144 KB of the 160 KB LDS
 // LDS with coalesced loads and then gathers from LDS.  The direct version below is bound by the
 // texture-address path (3 random 4-byte gathers per output: 0.65 TB/s measured at c = 256,
 // n = 16384); LDS serves the same random reads ~10x faster.  grid (ceil(c/CH), b)
+// T = payload type of points / out (float or bf16_t); the LDS image, the weights and the arithmetic are fp32.
+template <typename T>
 __global__ __launch_bounds__(1024) void three_interp_batch_fwd_lds_kernel(int c, int m, int n, int CH,
-                                                                          const float *__restrict__ points,
+                                                                          const T *__restrict__ points,
                                                                           const int *__restrict__ idx,
                                                                           const float *__restrict__ weight,
-                                                                          float *__restrict__ out) {
+                                                                          T *__restrict__ out) {
     extern __shared__ float rows[];  // [CH][m]
     const int c0 = blockIdx.x * CH, bs = blockIdx.y;
     const int nch = min(CH, c - c0);
-    const float *src = points + ((size_t)bs * c + c0) * m;
-    for (int i = threadIdx.x; i < nch * m; i += blockDim.x) rows[i] = src[i];
+    const T *src = points + ((size_t)bs * c + c0) * m;
+    for (int i = threadIdx.x; i < nch * m; i += blockDim.x) rows[i] = Payload<T>::ld(src + i);
     __syncthreads();
-    float *dst = out + ((size_t)bs * c + c0) * n;
+    T *dst = out + ((size_t)bs * c + c0) * n;
     for (int pt = threadIdx.x; pt < n; pt += blockDim.x) {
         const size_t o = ((size_t)bs * n + pt) * 3;
         const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
         const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
         for (int ch = 0; ch < nch; ++ch) {
             const float *r = rows + (size_t)ch * m;
-            dst[(size_t)ch * n + pt] = dot3_of(w0, r[i0], w1, r[i1], w2, r[i2]);
+            Payload<T>::st(dst + (size_t)ch * n + pt, dot3_of(w0, r[i0], w1, r[i1], w2, r[i2]));
         }
     }
 }
@@ -280,11 +283,12 @@ __global__ __launch_bounds__(1024) void three_interp_batch_bwd_sorted_kernel(int
 }
 
 // direct forward (rows that do not fit LDS).  grid (ceil(n/256), ceil(c/TI_CCHUNK), b)
+template <typename T>
 __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int m, int n,
-                                                                     const float *__restrict__ points,
+                                                                     const T *__restrict__ points,
                                                                      const int *__restrict__ idx,
                                                                      const float *__restrict__ weight,
-                                                                     float *__restrict__ out) {
+                                                                     T *__restrict__ out) {
     const int pt = blockIdx.x * 256 + threadIdx.x;
     if (pt >= n) return;
     const int bs = blockIdx.z;
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int 
     const size_t o = ((size_t)bs * n + pt) * 3;
     const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
     const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
-    const float *src = points + ((size_t)bs * c + c0) * m;
-    float *dst = out + ((size_t)bs * c + c0) * n + pt;
+    const T *src = points + ((size_t)bs * c + c0) * m;
+    T *dst = out + ((size_t)bs * c + c0) * n + pt;
     for (int ci = c0; ci < c1; ++ci) {
-        *dst = dot3_of(w0, src[i0], w1, src[i1], w2, src[i2]);
+        Payload<T>::st(dst, dot3_of(w0, Payload<T>::ld(src + i0), w1, Payload<T>::ld(src + i1), w2, Payload<T>::ld(src + i2)));
         src += m;
         dst += n;
     }
@@ -354,18 +358,20 @@ __global__ __launch_bounds__(256) void three_interp_batch_bwd_atomic_kernel(int 
 
 // ------------------------- three_interpolate, stack layout -------------------------
 // flat index e = pt*C + ci, lanes along c
+template <typename T>
 __global__ __launch_bounds__(256) void three_interp_stack_fwd_kernel(long long total, int C,
-                                                                     const float *__restrict__ features,
+                                                                     const T *__restrict__ features,
                                                                      const int *__restrict__ idx,
                                                                      const float *__restrict__ weight,
-                                                                     float *__restrict__ out) {
+                                                                     T *__restrict__ out) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long pt = e / C;
         const int ci = (int)(e - pt * C);
         const int i0 = idx[pt * 3], i1 = idx[pt * 3 + 1], i2 = idx[pt * 3 + 2];
         const float w0 = weight[pt * 3], w1 = weight[pt * 3 + 1], w2 = weight[pt * 3 + 2];
-        out[e] = dot3_of(w0, features[(size_t)i0 * C + ci], w1, features[(size_t)i1 * C + ci], w2,
-                         features[(size_t)i2 * C + ci]);
+        Payload<T>::st(out + e, dot3_of(w0, Payload<T>::ld(features + (size_t)i0 * C + ci), w1,
+                                        Payload<T>::ld(features + (size_t)i1 * C + ci), w2,
+                                        Payload<T>::ld(features + (size_t)i2 * C + ci)));
     }
 }
 
@@ -395,7 +401,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_nn_batch(int b,
     if (b == 0 || n == 0) return MGAR_OK;
     MGAR_REQUIRE(unknown && dist2 && idx && (known || m == 0), "three_nn_batch: null pointer");
     dim3 grid(ceil_div(n, TN_THREADS), b);
-    KtScope kt(KT_THREE_NN, (hipStream_t)stream, (double)b * (12.0 * n + 12.0 * m + 24.0 * n));
+    KtScope kt(KT_THREE_NN, (hipStream_t)stream, (double)b * (12.0 * n + 12.0 * m + 24.0 * n), 8.0 * b * (double)n * m);
     hipLaunchKernelGGL(three_nn_kernel<false>, grid, dim3(TN_THREADS), 0, (hipStream_t)stream, b, n, m, unknown,
                        (const int *)nullptr, known, (const int *)nullptr, dist2, idx);
     return check_launch("three_nn_batch: launch failed");
@@ -415,31 +421,43 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_nn_stack(int ba
     return check_launch("three_nn_stack: launch failed");
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch(int b, int c, int m, int n, const float *points, const int *idx,
-                                            const float *weight, float *out, void *stream) {
+template <typename T>
+static int three_interpolate_batch_impl(int b, int c, int m, int n, const T *points, const int *idx, const float *weight, T *out,
+                                        void *stream) {
     MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_batch: negative size");
     MGAR_REQUIRE(b <= 65535, "three_interpolate_batch: b > 65535");
     if ((long long)b * c * n == 0) return MGAR_OK;
     MGAR_REQUIRE(points && idx && weight && out, "three_interpolate_batch: null pointer");
-    KtScope kt(KT_THREE_INTERP_FWD, (hipStream_t)stream, (double)b * (24.0 * n + 16.0 * c * n));
+    // minimum traffic: the source rows once, the outputs once, idx + weight (24 B per unknown point)
+    KtScope kt(KT_THREE_INTERP_FWD, (hipStream_t)stream, (double)b * (24.0 * n + (double)sizeof(T) * c * ((double)m + n)));
     if (m <= TI_LDS_MAX_FLOATS) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)three_interp_batch_fwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute((const void *)three_interp_batch_fwd_lds_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       TI_LDS_MAX_FLOATS * (int)sizeof(float));
             attr_set = true;
         }
         int ch = TI_LDS_MAX_FLOATS / m;
         ch = ch > 8 ? 8 : ch;
         while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
-        hipLaunchKernelGGL(three_interp_batch_fwd_lds_kernel, dim3(ceil_div(c, ch), b), dim3(n >= 4096 ? 1024 : 256),
+        hipLaunchKernelGGL(three_interp_batch_fwd_lds_kernel<T>, dim3(ceil_div(c, ch), b), dim3(n >= 4096 ? 1024 : 256),
                            (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, m, n, ch, points, idx, weight, out);
     } else {
         dim3 grid(ceil_div(n, 256), ceil_div(c, TI_CCHUNK), b);
-        hipLaunchKernelGGL(three_interp_batch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx,
+        hipLaunchKernelGGL(three_interp_batch_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx,
                            weight, out);
     }
     return check_launch("three_interpolate_batch: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch(int b, int c, int m, int n, const float *points, const int *idx,
+                                            const float *weight, float *out, void *stream) {
+    return three_interpolate_batch_impl<float>(b, c, m, n, points, idx, weight, out, stream);
+}
+// bf16 payload: points / out address bf16 elements; idx int32, weight fp32
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_bf16(int b, int c, int m, int n, const void *points, const int *idx,
+                                            const float *weight, void *out, void *stream) {
+    return three_interpolate_batch_impl<bf16_t>(b, c, m, n, (const bf16_t *)points, idx, weight, (bf16_t *)out, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
@@ -471,16 +489,24 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
     return check_launch("three_interpolate_grad_batch: launch failed");
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_stack(int N, int C, const float *features, const int *idx, const float *weight,
-                                            float *out, void *stream) {
+template <typename T>
+static int three_interpolate_stack_impl(int N, int C, const T *features, const int *idx, const float *weight, T *out, void *stream) {
     MGAR_REQUIRE(N >= 0 && C >= 0, "three_interpolate_stack: negative size");
     const long long total = (long long)N * C;
     if (total == 0) return MGAR_OK;
     MGAR_REQUIRE(features && idx && weight && out, "three_interpolate_stack: null pointer");
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    hipLaunchKernelGGL(three_interp_stack_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, C,
+    hipLaunchKernelGGL(three_interp_stack_fwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, C,
                        features, idx, weight, out);
     return check_launch("three_interpolate_stack: launch failed");
+}
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_stack(int N, int C, const float *features, const int *idx, const float *weight,
+                                            float *out, void *stream) {
+    return three_interpolate_stack_impl<float>(N, C, features, idx, weight, out, stream);
+}
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_stack_bf16(int N, int C, const void *features, const int *idx,
+                                            const float *weight, void *out, void *stream) {
+    return three_interpolate_stack_impl<bf16_t>(N, C, (const bf16_t *)features, idx, weight, (bf16_t *)out, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_stack(int N, int C, const float *grad_out, const int *idx,
@@ -524,7 +550,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
     ch = ch >= 8 ? 8 : (ch >= 4 ? 4 : (ch >= 2 ? 2 : 1));
     while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
     hipStream_t st = (hipStream_t)stream;
-    KtScope kt(KT_THREE_INTERP_BWD, st, (double)b * (24.0 * n + 16.0 * c * n));
+    KtScope kt(KT_THREE_INTERP_BWD, st, (double)b * (24.0 * n + 4.0 * c * m + 4.0 * c * n));   // grad_out once, grad_points once, the 3n-entry list
     if (ch == 8) launch_bwd_sorted<8>(b, c, n, m, grad_out, list, grad_points, st);
     else if (ch == 4) launch_bwd_sorted<4>(b, c, n, m, grad_out, list, grad_points, st);
     else if (ch == 2) launch_bwd_sorted<2>(b, c, n, m, grad_out, list, grad_points, st);

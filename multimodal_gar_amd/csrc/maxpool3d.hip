@@ -14,6 +14,7 @@
 // loads one aligned 16-byte vector (two for stride 2) plus the one or two edge elements and forms the four
 // horizontal maxima in registers.  A one-thread-per-output kernel covers the other geometries.
 #include "common.hpp"
+#include "payload.hpp"
 
 namespace mgar {
 
@@ -22,8 +23,9 @@ struct Pool3dGeom {
     int kt, kh, kw, st, sh, sw, pt, ph, pw;  // p* = FRONT padding of each axis
 };
 
-__global__ __launch_bounds__(256) void maxpool3d_same_kernel(const float *__restrict__ x, long long total, Pool3dGeom g,
-                                                             float *__restrict__ y) {
+template <typename T>   // payload type: float or bf16_t (max of widened values is exact: bf16 in, bf16 out loses nothing)
+__global__ __launch_bounds__(256) void maxpool3d_same_kernel(const T *__restrict__ x, long long total, Pool3dGeom g,
+                                                             T *__restrict__ y) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int wo = (int)(e % g.Wo);
         long long r = e / g.Wo;
@@ -34,13 +36,13 @@ __global__ __launch_bounds__(256) void maxpool3d_same_kernel(const float *__rest
         const int t1 = t0 + g.kt, h1 = h0 + g.kh, w1 = w0 + g.kw;
         const bool pad = t0 < 0 || h0 < 0 || w0 < 0 || t1 > g.T || h1 > g.H || w1 > g.W;
         float best = pad ? 0.f : -__builtin_inff();  // zero padding takes part in the max
-        const float *base = x + (size_t)nc * g.T * g.H * g.W;
+        const T *base = x + (size_t)nc * g.T * g.H * g.W;
         for (int t = max(t0, 0); t < min(t1, g.T); ++t)
             for (int h = max(h0, 0); h < min(h1, g.H); ++h) {
-                const float *row = base + ((size_t)t * g.H + h) * g.W;
-                for (int w = max(w0, 0); w < min(w1, g.W); ++w) best = fmaxf(best, row[w]);
+                const T *row = base + ((size_t)t * g.H + h) * g.W;
+                for (int w = max(w0, 0); w < min(w1, g.W); ++w) best = fmaxf(best, Payload<T>::ld(row + w));
             }
-        y[e] = best;
+        Payload<T>::st(y + e, best);
     }
 }
 
@@ -50,8 +52,8 @@ __global__ __launch_bounds__(256) void maxpool3d_same_kernel(const float *__rest
 // keeps the last three of them in registers; an output slice is emitted when its last input slice has been seen.
 // Every input element is loaded once per (kh x kw) window it belongs to -- 9 loads per output quad instead of 27
 // for the 3x3x3 pools, and the t-reuse no longer depends on the L2.  grid (ceil(Ho * Wo/4 / 256), NC)
-template <int SW>
-__global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__restrict__ x, Pool3dGeom g, float *__restrict__ y) {
+template <int SW, typename T>
+__global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const T *__restrict__ x, Pool3dGeom g, T *__restrict__ y) {
     const int nq = g.Wo >> 2;
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int ho = q / nq, wq = q - ho * nq;
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__
     const int h0 = ho * g.sh - g.ph, h1 = h0 + g.kh;
     const bool pad_h = h0 < 0 || h1 > g.H;
     const float ninf = -__builtin_inff();
-    const float *base = x + nc * g.T * g.H * g.W;
+    const T *base = x + nc * g.T * g.H * g.W;
     const int wb = wq * 4 * SW;  // first aligned input column of this quad
     const bool pad_l = SW == 1 && wb == 0;
     const bool pad_r = SW == 1 ? (wb + 4 >= g.W) : (wb + 8 >= g.W);
@@ -70,19 +72,19 @@ __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__
         p0 = p1; p1 = p2;
         float b0 = ninf, b1 = ninf, b2 = ninf, b3 = ninf;
         for (int h = max(h0, 0); h < min(h1, g.H); ++h) {
-            const float *row = base + ((size_t)t * g.H + h) * g.W + wb;
+            const T *row = base + ((size_t)t * g.H + h) * g.W + wb;
             if (SW == 1) {  // outputs j = 0..3 cover inputs wb + j - 1 .. wb + j + 1
-                const float4 v = *reinterpret_cast<const float4 *>(row);
-                const float lft = wb > 0 ? row[-1] : ninf;
-                const float rgt = wb + 4 < g.W ? row[4] : ninf;
+                const float4 v = Payload<T>::ld4(row);
+                const float lft = wb > 0 ? Payload<T>::ld(row - 1) : ninf;
+                const float rgt = wb + 4 < g.W ? Payload<T>::ld(row + 4) : ninf;
                 b0 = fmaxf(b0, fmaxf(fmaxf(lft, v.x), v.y));
                 b1 = fmaxf(b1, fmaxf(fmaxf(v.x, v.y), v.z));
                 b2 = fmaxf(b2, fmaxf(fmaxf(v.y, v.z), v.w));
                 b3 = fmaxf(b3, fmaxf(fmaxf(v.z, v.w), rgt));
             } else {        // outputs j cover inputs wb + 2j .. wb + 2j + 2
-                const float4 v = *reinterpret_cast<const float4 *>(row);
-                const float4 u = *reinterpret_cast<const float4 *>(row + 4);
-                const float rgt = wb + 8 < g.W ? row[8] : ninf;
+                const float4 v = Payload<T>::ld4(row);
+                const float4 u = Payload<T>::ld4(row + 4);
+                const float rgt = wb + 8 < g.W ? Payload<T>::ld(row + 8) : ninf;
                 b0 = fmaxf(b0, fmaxf(fmaxf(v.x, v.y), v.z));
                 b1 = fmaxf(b1, fmaxf(fmaxf(v.z, v.w), u.x));
                 b2 = fmaxf(b2, fmaxf(fmaxf(u.x, u.y), u.z));
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__
             if (pad || pad_l) r.x = fmaxf(r.x, 0.f);
             if (pad) { r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); }
             if (pad || pad_r) r.w = fmaxf(r.w, 0.f);
-            *reinterpret_cast<float4 *>(y + ((nc * g.To + to) * g.Ho + ho) * g.Wo + wq * 4) = r;
+            Payload<T>::st4(y + ((nc * g.To + to) * g.Ho + ho) * g.Wo + wq * 4, r);
             ++to;
         }
     }
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const float *__
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd(const float *x, int NC, int T, int H, int W,
-                                                                             int kt, int kh, int kw, int st, int sh, int sw,
-                                                                             float *y, void *stream) {
+template <typename T_>
+static int maxpool3d_same_fwd_impl(const T_ *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, T_ *y,
+                                   void *stream) {
     MGAR_REQUIRE(NC >= 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
                  "maxpool3d_same_fwd: bad sizes");
     if (NC == 0) return MGAR_OK;
@@ -125,16 +127,26 @@ extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd(co
     };
     Pool3dGeom g{T, H, W, (T + st - 1) / st, (H + sh - 1) / sh, (W + sw - 1) / sw, kt, kh, kw, st, sh, sw,
                  front(T, kt, st), front(H, kh, sh), front(W, kw, sw)};
-    KtScope ktimer(KT_MAXPOOL3D, (hipStream_t)stream, 4.0 * NC * ((double)T * H * W + (double)g.To * g.Ho * g.Wo));
+    KtScope ktimer(KT_MAXPOOL3D, (hipStream_t)stream, (double)sizeof(T_) * NC * ((double)T * H * W + (double)g.To * g.Ho * g.Wo));
     const bool vec1 = kw == 3 && sw == 1 && g.pw == 1, vec2 = kw == 3 && sw == 2 && g.pw == 0 && W % 2 == 0;
     if ((vec1 || vec2) && kt <= 3 && W % 4 == 0 && g.Wo % 4 == 0 && NC <= 65535 && (!vec2 || W >= 8)) {
         dim3 grid(ceil_div(g.Ho * (g.Wo / 4), 256), NC);
-        if (vec1) hipLaunchKernelGGL(maxpool3d_same_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
-        else hipLaunchKernelGGL(maxpool3d_same_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
+        if (vec1) hipLaunchKernelGGL((maxpool3d_same_vec_kernel<1, T_>), grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
+        else hipLaunchKernelGGL((maxpool3d_same_vec_kernel<2, T_>), grid, dim3(256), 0, (hipStream_t)stream, x, g, y);
         return check_launch("maxpool3d_same_fwd: launch failed");
     }
     const long long total = (long long)NC * g.To * g.Ho * g.Wo;
     const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-    hipLaunchKernelGGL(maxpool3d_same_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, total, g, y);
+    hipLaunchKernelGGL(maxpool3d_same_kernel<T_>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, total, g, y);
     return check_launch("maxpool3d_same_fwd: launch failed");
+}
+
+extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd(const float *x, int NC, int T, int H, int W, int kt, int kh,
+                                                                             int kw, int st, int sh, int sw, float *y, void *stream) {
+    return maxpool3d_same_fwd_impl<float>(x, NC, T, H, W, kt, kh, kw, st, sh, sw, y, stream);
+}
+extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd_bf16(const void *x, int NC, int T, int H, int W, int kt,
+                                                                                  int kh, int kw, int st, int sh, int sw, void *y,
+                                                                                  void *stream) {
+    return maxpool3d_same_fwd_impl<bf16_t>((const bf16_t *)x, NC, T, H, W, kt, kh, kw, st, sh, sw, (bf16_t *)y, stream);
 }

@@ -24,6 +24,7 @@
 //   * every wave owns whole 128-column tiles and software-pipelines them: the loads of the next
 //     16-channel slab are in flight while the MFMAs of the current one run.
 #include "common.hpp"
+#include "payload.hpp"
 
 namespace mgar {
 
@@ -34,18 +35,19 @@ constexpr int PF_COLS = 128;  // columns per wave tile
 // registers + two slab buffers stay under 256 VGPRs (2 waves per SIMD instead of 1)
 template <int OB> struct PfSlab { static constexpr int KC = OB == 1 ? 16 : 8; };
 
+template <typename T>
 struct PfArgs {
-    const float *x;
+    const T *x;                                 // payload: float or bf16_t (fp32 accumulation on the fp32 MFMA either way)
     const float *w;
     const float *mean, *invstd, *gamma, *beta;  // input activation (mean == nullptr: identity)
-    float *y;
+    T *y;
     int B, Cin, Cout, P;
     int w_rs, w_cs;  // W[o, i] = w[o * w_rs + i * w_cs]
     int relu;
 };
 
-template <int OB>
-__global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
+template <int OB, typename T>
+__global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs<T> a) {
     constexpr int PF_KC = PfSlab<OB>::KC, KS = PF_KC / 2;
     constexpr int WLD = OB == 1 ? 32 : 96;  // LDS row stride of W: the two half-waves hit disjoint banks
     extern __shared__ float lds[];          // [nkc*16][WLD] weights, then [nkc*16][4] (sc, sh, mu, -)
@@ -91,11 +93,11 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
         const int kc = (int)(s % nkc);
         const int b = (int)(t / tiles_per_b);
         const int p = (int)(t - (long long)b * tiles_per_b) * PF_COLS + 4 * l;
-        const float *src = a.x + ((size_t)b * a.Cin + kc * PF_KC + h) * a.P + p;
+        const T *src = a.x + ((size_t)b * a.Cin + kc * PF_KC + h) * a.P + p;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int ch = kc * PF_KC + 2 * ks + h;
-            buf[ks] = (ch < a.Cin && p < a.P) ? *reinterpret_cast<const float4 *>(src + (size_t)2 * ks * a.P)
+            buf[ks] = (ch < a.Cin && p < a.P) ? Payload<T>::ld4(src + (size_t)2 * ks * a.P)
                                               : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (o < a.Cout && p < a.P)
-                        *reinterpret_cast<float4 *>(a.y + ((size_t)b * a.Cout + o) * a.P + p) =
-                            make_float4(acc[ob][0][r], acc[ob][1][r], acc[ob][2][r], acc[ob][3][r]);
+                        Payload<T>::st4(a.y + ((size_t)b * a.Cout + o) * a.P + p,
+                                        make_float4(acc[ob][0][r], acc[ob][1][r], acc[ob][2][r], acc[ob][3][r]));
                     acc[ob][0][r] = 0.f; acc[ob][1][r] = 0.f; acc[ob][2][r] = 0.f; acc[ob][3][r] = 0.f;
                 }
         }
@@ -150,31 +152,30 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs a) {
     }
 }
 
-template <int OB>
-static void launch_pf(const PfArgs &a, hipStream_t st) {
+template <int OB, typename T>
+static void launch_pf(const PfArgs<T> &a, hipStream_t st) {
     constexpr int WLD = OB == 1 ? 32 : 96, PF_KC = PfSlab<OB>::KC;
     const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
     const int lds = nkc * PF_KC * (WLD + 4) * (int)sizeof(float);
     static int attr_lds = 0;
     if (lds > 65536 && lds > attr_lds) {
-        (void)hipFuncSetAttribute((const void *)pointwise_fwd_kernel<OB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)pointwise_fwd_kernel<OB, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_lds = lds;
     }
     const long long ntiles = (long long)a.B * ((a.P + PF_COLS - 1) / PF_COLS);
     long long wgs = (ntiles + 3) / 4;
     if (wgs > 2048) wgs = 2048;   // 8 workgroups per CU; waves stride over the tiles
-    hipLaunchKernelGGL((pointwise_fwd_kernel<OB>), dim3((unsigned)wgs), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pointwise_fwd_kernel<OB, T>), dim3((unsigned)wgs), dim3(256), lds, st, a);
 }
 
 }  // namespace mgar
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *w,
-                                                                             int w_row_stride, int w_col_stride, int Cout,
-                                                                             const float *in_mean, const float *in_invstd,
-                                                                             const float *in_gamma, const float *in_beta,
-                                                                             int in_relu, float *y, void *stream) {
+template <typename T>
+static int pointwise_conv_fwd_impl(const T *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride, int Cout,
+                                   const float *in_mean, const float *in_invstd, const float *in_gamma, const float *in_beta,
+                                   int in_relu, T *y, void *stream) {
     MGAR_REQUIRE(B >= 0 && Cin >= 0 && Cout >= 0 && P >= 0, "pointwise_conv_fwd: negative size");
     if ((long long)B * P == 0 || Cout == 0) return MGAR_OK;
     MGAR_REQUIRE(x && w && y, "pointwise_conv_fwd: null pointer");
@@ -183,10 +184,25 @@ extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_fwd(co
         set_error("pointwise_conv_fwd: needs 1 <= Cin <= 256, Cout <= 64 and P % 4 == 0 (use the library GEMM otherwise)");
         return MGAR_EUNSUPPORTED;
     }
-    PfArgs a{x, w, in_mean, in_invstd, in_gamma, in_beta, y, B, Cin, Cout, P, w_row_stride, w_col_stride, in_relu};
+    PfArgs<T> a{x, w, in_mean, in_invstd, in_gamma, in_beta, y, B, Cin, Cout, P, w_row_stride, w_col_stride, in_relu};
     hipStream_t st = (hipStream_t)stream;
-    KtScope kt(KT_POINTWISE_FWD, st, 4.0 * (double)B * P * (Cin + Cout), 2.0 * (double)B * P * Cin * Cout);
-    if (Cout <= 32) launch_pf<1>(a, st);
-    else launch_pf<2>(a, st);
+    KtScope kt(KT_POINTWISE_FWD, st, (double)sizeof(T) * B * P * (Cin + Cout), 2.0 * (double)B * P * Cin * Cout);
+    if (Cout <= 32) launch_pf<1, T>(a, st);
+    else launch_pf<2, T>(a, st);
     return check_launch("pointwise_conv_fwd: launch failed");
+}
+
+#define PF_API extern "C" __attribute__((visibility("default")))
+PF_API int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride, int Cout,
+                                   const float *in_mean, const float *in_invstd, const float *in_gamma, const float *in_beta,
+                                   int in_relu, float *y, void *stream) {
+    return pointwise_conv_fwd_impl<float>(x, B, Cin, P, w, w_row_stride, w_col_stride, Cout, in_mean, in_invstd, in_gamma, in_beta,
+                                          in_relu, y, stream);
+}
+// bf16 payload (x, y address bf16 elements; W and the BatchNorm vectors stay fp32)
+PF_API int mgar_pointwise_conv_fwd_bf16(const void *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride,
+                                        int Cout, const float *in_mean, const float *in_invstd, const float *in_gamma,
+                                        const float *in_beta, int in_relu, void *y, void *stream) {
+    return pointwise_conv_fwd_impl<bf16_t>((const bf16_t *)x, B, Cin, P, w, w_row_stride, w_col_stride, Cout, in_mean, in_invstd,
+                                           in_gamma, in_beta, in_relu, (bf16_t *)y, stream);
 }

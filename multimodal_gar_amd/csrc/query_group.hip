@@ -20,6 +20,7 @@
 // The stack kernels consume the RAW ball-query output (idx[row][0] == -1 marks an empty ball,
 // pointnet2_stack/src/ball_query_gpu.cu:65) so the host needs no mask / fix-up passes either.
 #include "common.hpp"
+#include "payload.hpp"
 
 namespace mgar {
 
@@ -33,13 +34,15 @@ constexpr int QG_CCHUNK = 8;
 // two tensors, or rows 0..2 / 3.. of one (b, 3+c, npoints, nsample) tensor.
 // wx (c, 3), optional: y[c] += wx[c] . rel  -- the xyz half of a first MLP layer whose feature
 // half was applied to the un-grouped features beforehand ("project, then group").
+// T = payload type of features / rel_out / y_out (float or bf16_t); xyz, new_xyz, wx and the arithmetic are fp32.
+template <typename T>
 __global__ __launch_bounds__(256) void qg_batch_fwd_kernel(int c, int n, int npoints, int nsample,
                                                            const float *__restrict__ xyz,
                                                            const float *__restrict__ new_xyz,
-                                                           const float *__restrict__ features,
+                                                           const T *__restrict__ features,
                                                            const float *__restrict__ wx,
-                                                           const int *__restrict__ idx, float *__restrict__ rel_out,
-                                                           size_t rel_bstride, float *__restrict__ y_out, size_t y_bstride) {
+                                                           const int *__restrict__ idx, T *__restrict__ rel_out,
+                                                           size_t rel_bstride, T *__restrict__ y_out, size_t y_bstride) {
     const int cols = npoints * nsample;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= cols) return;
@@ -54,22 +57,22 @@ __global__ __launch_bounds__(256) void qg_batch_fwd_kernel(int c, int n, int npo
     }
     if (blockIdx.y == 0) {
         if (rel_out) {
-            float *dst = rel_out + (size_t)bs * rel_bstride + col;
-            dst[0] = r0;
-            dst[(size_t)cols] = r1;
-            dst[(size_t)2 * cols] = r2;
+            T *dst = rel_out + (size_t)bs * rel_bstride + col;
+            Payload<T>::st(dst, r0);
+            Payload<T>::st(dst + (size_t)cols, r1);
+            Payload<T>::st(dst + (size_t)2 * cols, r2);
         }
         return;
     }
     const int c0 = (blockIdx.y - 1) * QG_CCHUNK;
     const int c1 = min(c0 + QG_CCHUNK, c);
-    const float *src = features + ((size_t)bs * c + c0) * n + k;
-    float *dst = y_out + (size_t)bs * y_bstride + (size_t)c0 * cols + col;
+    const T *src = features + ((size_t)bs * c + c0) * n + k;
+    T *dst = y_out + (size_t)bs * y_bstride + (size_t)c0 * cols + col;
 #pragma unroll 4
     for (int ci = c0; ci < c1; ++ci) {
-        float v = *src;
+        float v = Payload<T>::ld(src);
         if (wx) v += wx[ci * 3 + 0] * r0 + wx[ci * 3 + 1] * r1 + wx[ci * 3 + 2] * r2;
-        *dst = v;
+        Payload<T>::st(dst, v);
         src += n;
         dst += cols;
     }
@@ -144,13 +147,14 @@ __device__ __forceinline__ int qs_prologue(QsTile &t, int B, int M, int nsample,
     return ncol;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, int nsample, const float *__restrict__ xyz,
                                                            const int *__restrict__ xyz_batch_cnt,
                                                            const float *__restrict__ new_xyz,
                                                            const int *__restrict__ new_xyz_batch_cnt,
-                                                           const float *__restrict__ features, int ld,
+                                                           const T *__restrict__ features, int ld,
                                                            const float *__restrict__ wx, const int *__restrict__ idx,
-                                                           float *__restrict__ rel_out, float *__restrict__ y_out) {
+                                                           T *__restrict__ rel_out, T *__restrict__ y_out) {
     __shared__ QsTile t;
     int col0;
     const int ncol = qs_prologue(t, B, M, nsample, idx, new_xyz_batch_cnt, xyz_batch_cnt, col0);
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
         const int m = (col0 + cl) / nsample;
         const float v = src < 0 ? 0.f : xyz[(size_t)src * 3 + r] - new_xyz[(size_t)m * 3 + r];
         t.rel[cl][r] = v;
-        if (rel_out) rel_out[(size_t)r * ms + col0 + cl] = v;
+        if (rel_out) Payload<T>::st(rel_out + (size_t)r * ms + col0 + cl, v);
     }
     __syncthreads();
     // rows of y_out: features (+ wx . rel), QS_CH channels per pass through the LDS tile
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
             const int src = t.src_row[cl];
             float v = 0.f;
             if (src >= 0 && ci < nch) {
-                v = features[(size_t)src * ld + c0 + ci];
+                v = Payload<T>::ld(features + (size_t)src * ld + c0 + ci);
                 if (wx) {
                     const float *w = wx + (size_t)(c0 + ci) * 3;
                     v += w[0] * t.rel[cl][0] + w[1] * t.rel[cl][1] + w[2] * t.rel[cl][2];
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
         __syncthreads();
         for (int e = threadIdx.x; e < nch * QS_COLS; e += 256) {     // lanes along the columns
             const int ci = e / QS_COLS, cl = e - ci * QS_COLS;
-            if (cl < ncol) y_out[(size_t)(c0 + ci) * ms + col0 + cl] = t.tile[cl][ci];
+            if (cl < ncol) Payload<T>::st(y_out + (size_t)(c0 + ci) * ms + col0 + cl, t.tile[cl][ci]);
         }
         __syncthreads();
     }
@@ -223,17 +227,18 @@ using namespace mgar;
 
 #define QG_API extern "C" __attribute__((visibility("default")))
 
+template <typename T>
 static int qg_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
-                        const float *features, const float *wx, const int *idx, float *rel_out, size_t rel_bstride,
-                        float *y_out, size_t y_bstride, void *stream, const char *what) {
+                        const T *features, const float *wx, const int *idx, T *rel_out, size_t rel_bstride,
+                        T *y_out, size_t y_bstride, void *stream, const char *what) {
     MGAR_REQUIRE(b >= 0 && c >= 0 && n >= 0 && npoints >= 0 && nsample >= 0, "query_group (batch) fwd: negative size");
     MGAR_REQUIRE(b <= 65535, "query_group (batch) fwd: b > 65535");
     if ((long long)b * npoints * nsample == 0) return MGAR_OK;
     MGAR_REQUIRE(xyz && new_xyz && idx && (features || c == 0) && (y_out || c == 0) && (rel_out || y_out),
                  "query_group (batch) fwd: null pointer");
     dim3 grid(ceil_div((long long)npoints * nsample, 256), 1 + ceil_div(c, QG_CCHUNK), b);
-    KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)b * npoints * nsample * (4.0 + 8.0 * (c + 3)));
-    hipLaunchKernelGGL(qg_batch_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, nsample, xyz, new_xyz,
+    KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)b * npoints * nsample * (4.0 + (double)sizeof(T) * (c + 3)));   // idx + the grouped tensor written once (source rows: cache-resident)
+    hipLaunchKernelGGL(qg_batch_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, c, n, npoints, nsample, xyz, new_xyz,
                        features, wx, idx, rel_out, rel_bstride, y_out, y_bstride);
     return check_launch(what);
 }
@@ -245,7 +250,7 @@ static int qg_batch_bwd(int b, int c, int n, int npoints, int nsample, const flo
     const int cols = npoints * nsample;
     if ((long long)b * c * cols == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_y && idx && grad_features, "query_group (batch) bwd: null pointer");
-    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)b * cols * (4.0 + 8.0 * c));
+    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)b * cols * (4.0 + 4.0 * c));
     if (n <= QG_LDS_MAX_FLOATS) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -265,8 +270,8 @@ static int qg_batch_bwd(int b, int c, int n, int npoints, int nsample, const flo
 QG_API int mgar_query_group_batch_fwd(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
                                       const float *features, const int *idx, float *out, void *stream) {
     const size_t cols = (size_t)npoints * nsample;
-    return qg_batch_fwd(b, c, n, npoints, nsample, xyz, new_xyz, features, nullptr, idx, out, (3 + c) * cols,
-                        out ? out + 3 * cols : nullptr, (3 + c) * cols, stream, "query_group_batch_fwd: launch failed");
+    return qg_batch_fwd<float>(b, c, n, npoints, nsample, xyz, new_xyz, features, nullptr, idx, out, (3 + c) * cols,
+                               out ? out + 3 * cols : nullptr, (3 + c) * cols, stream, "query_group_batch_fwd: launch failed");
 }
 
 QG_API int mgar_query_group_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_out, const int *idx,
@@ -281,8 +286,8 @@ QG_API int mgar_query_group_proj_batch_fwd(int b, int c, int n, int npoints, int
                                            float *rel_out, float *y_out, void *stream) {
     MGAR_REQUIRE(wx && zf && y_out, "query_group_proj_batch_fwd: null pointer");
     const size_t cols = (size_t)npoints * nsample;
-    return qg_batch_fwd(b, c, n, npoints, nsample, xyz, new_xyz, zf, wx, idx, rel_out, 3 * cols, y_out, (size_t)c * cols, stream,
-                        "query_group_proj_batch_fwd: launch failed");
+    return qg_batch_fwd<float>(b, c, n, npoints, nsample, xyz, new_xyz, zf, wx, idx, rel_out, 3 * cols, y_out, (size_t)c * cols,
+                               stream, "query_group_proj_batch_fwd: launch failed");
 }
 
 QG_API int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int nsample, const float *grad_y, const int *idx,
@@ -291,16 +296,17 @@ QG_API int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int
                         "query_group_proj_batch_bwd: launch failed");
 }
 
+template <typename T>
 static int qg_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt, const float *new_xyz,
-                        const int *new_xyz_batch_cnt, const float *features, int ld, const float *wx, const int *idx,
-                        float *rel_out, float *y_out, void *stream, const char *what) {
+                        const int *new_xyz_batch_cnt, const T *features, int ld, const float *wx, const int *idx,
+                        T *rel_out, T *y_out, void *stream, const char *what) {
     MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group (stack) fwd: negative size");
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0) return MGAR_OK;
     MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && (features || C == 0) && (y_out || C == 0) &&
                      (rel_out || y_out), "query_group (stack) fwd: null pointer");
-    KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)total * (4.0 + 8.0 * (C + 3)));
-    hipLaunchKernelGGL(qg_stack_fwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
+    KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)total * (4.0 + (double)sizeof(T) * (C + 3)));
+    hipLaunchKernelGGL(qg_stack_fwd_kernel<T>, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
                        xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, ld, wx, idx, rel_out, y_out);
     return check_launch(what);
 }
@@ -311,7 +317,7 @@ static int qg_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, c
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0 || C == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_y && idx && new_xyz_batch_cnt && xyz_batch_cnt && grad_features, "query_group (stack) bwd: null pointer");
-    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)total * (4.0 + 8.0 * C));
+    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)total * (4.0 + 4.0 * C));
     hipLaunchKernelGGL(qg_stack_bwd_kernel, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
                        grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_features, ld);
     return check_launch(what);
@@ -321,8 +327,8 @@ QG_API int mgar_query_group_stack_fwd(int B, int M, int C, int nsample, const fl
                                       const float *new_xyz, const int *new_xyz_batch_cnt, const float *features, const int *idx,
                                       float *out, void *stream) {
     const size_t ms = (size_t)M * nsample;
-    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, C, nullptr, idx, out,
-                        out ? out + 3 * ms : nullptr, stream, "query_group_stack_fwd: launch failed");
+    return qg_stack_fwd<float>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, C, nullptr, idx, out,
+                               out ? out + 3 * ms : nullptr, stream, "query_group_stack_fwd: launch failed");
 }
 
 QG_API int mgar_query_group_stack_bwd(int B, int M, int C, int nsample, const float *grad_out, const int *idx,
@@ -335,8 +341,8 @@ QG_API int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, con
                                            const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, int zf_ld,
                                            const float *wx, const int *idx, float *rel_out, float *y_out, void *stream) {
     MGAR_REQUIRE(wx && zf && y_out && zf_ld >= C, "query_group_proj_stack_fwd: null pointer or zf_ld < C");
-    return qg_stack_fwd(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, zf_ld, wx, idx, rel_out, y_out,
-                        stream, "query_group_proj_stack_fwd: launch failed");
+    return qg_stack_fwd<float>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, zf_ld, wx, idx, rel_out, y_out,
+                               stream, "query_group_proj_stack_fwd: launch failed");
 }
 
 QG_API int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
@@ -344,4 +350,37 @@ QG_API int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, con
                                            void *stream) {
     return qg_stack_bwd(B, M, C, nsample, grad_y, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, zf_ld, stream,
                         "query_group_proj_stack_bwd: launch failed");
+}
+
+// ---- bf16 payload twins of the forward entry points: features / zf / out / rel_out / y_out address bf16 elements; xyz, new_xyz,
+// wx and every index stay fp32 / int32 (index parity must not depend on the payload type) ----
+QG_API int mgar_query_group_batch_fwd_bf16(int b, int c, int n, int npoints, int nsample, const float *xyz, const float *new_xyz,
+                                           const void *features, const int *idx, void *out, void *stream) {
+    const size_t cols = (size_t)npoints * nsample;
+    bf16_t *o = (bf16_t *)out;
+    return qg_batch_fwd<bf16_t>(b, c, n, npoints, nsample, xyz, new_xyz, (const bf16_t *)features, nullptr, idx, o, (3 + c) * cols,
+                                o ? o + 3 * cols : nullptr, (3 + c) * cols, stream, "query_group_batch_fwd_bf16: launch failed");
+}
+QG_API int mgar_query_group_proj_batch_fwd_bf16(int b, int c, int n, int npoints, int nsample, const float *xyz,
+                                                const float *new_xyz, const void *zf, const float *wx, const int *idx,
+                                                void *rel_out, void *y_out, void *stream) {
+    MGAR_REQUIRE(wx && zf && y_out, "query_group_proj_batch_fwd_bf16: null pointer");
+    const size_t cols = (size_t)npoints * nsample;
+    return qg_batch_fwd<bf16_t>(b, c, n, npoints, nsample, xyz, new_xyz, (const bf16_t *)zf, wx, idx, (bf16_t *)rel_out, 3 * cols,
+                                (bf16_t *)y_out, (size_t)c * cols, stream, "query_group_proj_batch_fwd_bf16: launch failed");
+}
+QG_API int mgar_query_group_stack_fwd_bf16(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                           const float *new_xyz, const int *new_xyz_batch_cnt, const void *features,
+                                           const int *idx, void *out, void *stream) {
+    const size_t ms = (size_t)M * nsample;
+    bf16_t *o = (bf16_t *)out;
+    return qg_stack_fwd<bf16_t>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, (const bf16_t *)features, C, nullptr,
+                                idx, o, o ? o + 3 * ms : nullptr, stream, "query_group_stack_fwd_bf16: launch failed");
+}
+QG_API int mgar_query_group_proj_stack_fwd_bf16(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                                const float *new_xyz, const int *new_xyz_batch_cnt, const void *zf, int zf_ld,
+                                                const float *wx, const int *idx, void *rel_out, void *y_out, void *stream) {
+    MGAR_REQUIRE(wx && zf && y_out && zf_ld >= C, "query_group_proj_stack_fwd_bf16: null pointer or zf_ld < C");
+    return qg_stack_fwd<bf16_t>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, (const bf16_t *)zf, zf_ld, wx, idx,
+                                (bf16_t *)rel_out, (bf16_t *)y_out, stream, "query_group_proj_stack_fwd_bf16: launch failed");
 }

@@ -13,6 +13,7 @@
 // the same few cache lines; the (N,C,H,W) map of one clip (12 MB at 832x45x80) stays in L2 /
 // Infinity Cache across its RoIs.  Gather-bound; the backward scatters with float atomics.
 #include "common.hpp"
+#include "payload.hpp"
 
 namespace mgar {
 
@@ -60,27 +61,29 @@ __device__ __forceinline__ Taps bilinear_taps(int H, int W, float y, float x) {
     return t;
 }
 
-__global__ __launch_bounds__(256) void roi_align_fwd_kernel(long long total, const float *__restrict__ input, int C, int H,
+template <typename T>   // payload type of input / out; box geometry, tap weights and the accumulation are fp32
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(long long total, const T *__restrict__ input, int C, int H,
                                                             int W, const float *__restrict__ rois, int PH, int PW,
                                                             float scale, int sampling_ratio, int aligned,
-                                                            float *__restrict__ out) {
+                                                            T *__restrict__ out) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int pw = (int)(e % PW);
         const int ph = (int)((e / PW) % PH);
         const int c = (int)((e / ((long long)PW * PH)) % C);
         const int k = (int)(e / ((long long)PW * PH * C));
         const RoiGeom g = roi_geom(rois + (size_t)k * 5, scale, PH, PW, sampling_ratio, aligned);
-        const float *img = input + ((size_t)g.batch * C + c) * H * W;
+        const T *img = input + ((size_t)g.batch * C + c) * H * W;
         float acc = 0.f;
         for (int iy = 0; iy < g.gh; ++iy) {
             const float y = g.y1 + ph * g.bin_h + (iy + .5f) * g.bin_h / (float)g.gh;
             for (int ix = 0; ix < g.gw; ++ix) {
                 const float x = g.x1 + pw * g.bin_w + (ix + .5f) * g.bin_w / (float)g.gw;
                 const Taps t = bilinear_taps(H, W, y, x);
-                if (t.ok) acc += t.w1 * img[t.o1] + t.w2 * img[t.o2] + t.w3 * img[t.o3] + t.w4 * img[t.o4];
+                if (t.ok) acc += t.w1 * Payload<T>::ld(img + t.o1) + t.w2 * Payload<T>::ld(img + t.o2) + t.w3 * Payload<T>::ld(img + t.o3) +
+                                 t.w4 * Payload<T>::ld(img + t.o4);
             }
         }
-        out[e] = acc * g.inv_count;
+        Payload<T>::st(out + e, acc * g.inv_count);
     }
 }
 
@@ -120,19 +123,33 @@ static int roi_args_ok(int N, int C, int H, int W, int K, int ph, int pw) {
     return N >= 0 && C >= 0 && H > 0 && W > 0 && K >= 0 && ph > 0 && pw > 0;
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_roi_align_fwd(const float *input, int N, int C, int H, int W,
-                                                                        const float *rois, int K, int pooled_h,
-                                                                        int pooled_w, float spatial_scale,
-                                                                        int sampling_ratio, int aligned, float *out,
-                                                                        void *stream) {
+template <typename T>
+static int roi_align_fwd_impl(const T *input, int N, int C, int H, int W, const float *rois, int K, int pooled_h, int pooled_w,
+                              float spatial_scale, int sampling_ratio, int aligned, T *out, void *stream) {
     MGAR_REQUIRE(roi_args_ok(N, C, H, W, K, pooled_h, pooled_w), "roi_align_fwd: bad sizes");
     const long long total = (long long)K * C * pooled_h * pooled_w;
     if (total == 0) return MGAR_OK;
     MGAR_REQUIRE(input && rois && out, "roi_align_fwd: null pointer");
     const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
-    hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, input, C, H, W, rois,
+    hipLaunchKernelGGL(roi_align_fwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, input, C, H, W, rois,
                        pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
     return check_launch("roi_align_fwd: launch failed");
+}
+extern "C" __attribute__((visibility("default"))) int mgar_roi_align_fwd(const float *input, int N, int C, int H, int W,
+                                                                        const float *rois, int K, int pooled_h,
+                                                                        int pooled_w, float spatial_scale,
+                                                                        int sampling_ratio, int aligned, float *out,
+                                                                        void *stream) {
+    return roi_align_fwd_impl<float>(input, N, C, H, W, rois, K, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out, stream);
+}
+// bf16 payload: input / out address bf16 elements, rois stay fp32
+extern "C" __attribute__((visibility("default"))) int mgar_roi_align_fwd_bf16(const void *input, int N, int C, int H, int W,
+                                                                             const float *rois, int K, int pooled_h,
+                                                                             int pooled_w, float spatial_scale,
+                                                                             int sampling_ratio, int aligned, void *out,
+                                                                             void *stream) {
+    return roi_align_fwd_impl<bf16_t>((const bf16_t *)input, N, C, H, W, rois, K, pooled_h, pooled_w, spatial_scale, sampling_ratio,
+                                      aligned, (bf16_t *)out, stream);
 }
 
 extern "C" __attribute__((visibility("default"))) int mgar_roi_align_bwd(const float *grad_out, int N, int C, int H, int W,

@@ -61,4 +61,6 @@ def scene_offsets(counts, device):
 def dafm_attention(q, k, v, de_flat, scene_off, de_off, sigma, scale):
     """q, k, v: (rows, D) stacked over scenes; de_flat: concatenation of each scene's (n, n)
     distance matrix, row-major.  Returns (out (rows, D), att (same layout as de_flat))."""
-    return _DafmAttention.apply(q, k, v, de_flat, scene_off, de_off, sigma, scale)
+    # The per-scene attention tensors are tiny (A x 512 per scene): they stay fp32 on every configuration; under the bf16
+    # configurations (autocast) the projections that produce q / k / v run as bf16 GEMMs and are widened here.
+    return _DafmAttention.apply(q.float(), k.float(), v.float(), de_flat.float(), scene_off, de_off, sigma, scale)

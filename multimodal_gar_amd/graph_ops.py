@@ -118,8 +118,10 @@ class GATv2Conv(nn.Module):
         if self.training and self.dropout > 0:
             keep = 1.0 - self.dropout
             edge_scale = torch.bernoulli(torch.full((col.numel(), self.heads), keep, device=x.device)) / keep
-        out, alpha = _GatAggregate.apply(xl, xr, self.att.view(self.heads, self.out_channels), rowptr, col, edge_scale,
-                                         self.heads, self.negative_slope)
+        # node features of one actor graph are A x 4096 floats: the edge-softmax / aggregate kernel stays fp32 on every
+        # configuration (bf16 configurations: lin_l / lin_r run as bf16 GEMMs under autocast and are widened here)
+        out, alpha = _GatAggregate.apply(xl.float(), xr.float(), self.att.view(self.heads, self.out_channels).float(), rowptr, col,
+                                         edge_scale, self.heads, self.negative_slope)
         out = out if self.concat else out.view(n, self.heads, self.out_channels).mean(dim=1)
         if self.bias is not None:
             out = out + self.bias

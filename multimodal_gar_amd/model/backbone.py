@@ -44,14 +44,15 @@ class MaxPool3dSamePadding(nn.MaxPool3d):
         return sum(_same_pad_1d(s, self.kernel_size[dim], self.stride[dim]))
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad):
-            # forward-only fused kernel (csrc/maxpool3d.hip): no padded copy, no index tensor
+        if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not (torch.is_grad_enabled() and x.requires_grad):
+            # forward-only fused kernel (csrc/maxpool3d.hip): no padded copy, no index tensor; fp32 or bf16 payload
             from .. import _lib as L
             x = x.contiguous()
             n, c, t, h, w = x.shape
             (kt, kh, kw), (st, sh, sw) = self.kernel_size, self.stride
             y = torch.empty((n, c, -(-t // st), -(-h // sh), -(-w // sw)), dtype=x.dtype, device=x.device)
-            L.call("mgar_maxpool3d_same_fwd", L.fptr(x), n * c, t, h, w, kt, kh, kw, st, sh, sw, L.fptr(y), L.stream_of(x))
+            L.payload_call("mgar_maxpool3d_same_fwd", x.dtype, L.pptr(x, x.dtype), n * c, t, h, w, kt, kh, kw, st, sh, sw,
+                           L.pptr(y, x.dtype), L.stream_of(x))
             return y
         pads = _same_pads(x.shape[2:], self.kernel_size, self.stride)
         return super().forward(F.pad(x, _as_fpad(pads)))  # zero pad, as the reference

@@ -44,6 +44,10 @@ class PointNet2MSG(nn.Module):
         xyz = xyz.view(batch_size, -1, 3)
         if features is not None:
             features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous()
+            if features.is_cuda and torch.is_autocast_enabled():
+                # bf16 configurations: the per-point payload is bf16 from the start, so the grouped tensors of level 1 are
+                # written in bf16 by the fused query-and-group kernel (coordinates stay fp32)
+                features = features.to(torch.get_autocast_dtype('cuda'))
         l_xyz, l_features = [xyz], [features]
         # optional: centres picked ahead of time by the caller (same FPS, issued earlier so that it overlaps other
         # work -- one workgroup per cloud leaves most of the chip idle); SA modules take new_xyz as in the reference

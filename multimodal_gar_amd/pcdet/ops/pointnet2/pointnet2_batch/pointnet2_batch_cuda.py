@@ -71,8 +71,9 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
-    L.call("mgar_three_interpolate_batch", b, c, m, n, L.fptr(points), L.iptr(idx), L.fptr(weight), L.fptr(out),
-           L.stream_of(points))
+    dt = points.dtype          # feature payload: float32 or bfloat16 (idx int32, weight float32 either way)
+    L.payload_call("mgar_three_interpolate_batch", dt, b, c, m, n, L.pptr(points, dt), L.iptr(idx), L.fptr(weight), L.pptr(out, dt),
+                   L.stream_of(points))
     return 1
 
 
@@ -84,8 +85,9 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
 
 # ---- fused ops that are torch op chains in the reference (no pybind counterpart) ----
 def query_group_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, features, idx, out):
-    L.call("mgar_query_group_batch_fwd", b, c, n, npoints, nsample, L.fptr(xyz), L.fptr(new_xyz),
-           L.fptr(features) if features is not None else None, L.iptr(idx), L.fptr(out), L.stream_of(xyz))
+    dt = out.dtype             # payload type of features / out; xyz and new_xyz are float32
+    L.payload_call("mgar_query_group_batch_fwd", dt, b, c, n, npoints, nsample, L.fptr(xyz), L.fptr(new_xyz),
+                   L.pptr(features, dt) if features is not None else None, L.iptr(idx), L.pptr(out, dt), L.stream_of(xyz))
     return 1
 
 
@@ -96,8 +98,9 @@ def query_group_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_feat
 
 
 def query_group_proj_wrapper(b, c, n, npoints, nsample, xyz, new_xyz, zf, wx, idx, rel_out, y_out):
-    L.call("mgar_query_group_proj_batch_fwd", b, c, n, npoints, nsample, L.fptr(xyz), L.fptr(new_xyz), L.fptr(zf), L.fptr(wx),
-           L.iptr(idx), L.fptr(rel_out) if rel_out is not None else None, L.fptr(y_out), L.stream_of(xyz))
+    dt = zf.dtype              # payload type of zf / rel_out / y_out; xyz, new_xyz, wx are float32
+    L.payload_call("mgar_query_group_proj_batch_fwd", dt, b, c, n, npoints, nsample, L.fptr(xyz), L.fptr(new_xyz), L.pptr(zf, dt),
+                   L.fptr(wx), L.iptr(idx), L.pptr(rel_out, dt) if rel_out is not None else None, L.pptr(y_out, dt), L.stream_of(xyz))
     return 1
 
 

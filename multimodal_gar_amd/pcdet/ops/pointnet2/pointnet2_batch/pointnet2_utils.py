@@ -62,7 +62,9 @@ class GatherOperation(Function):
         batch, npoint = idx.size()
         _, chans, n_pts = features.size()
         out = _new(features, (batch, chans, npoint), torch.float32)
-        pointnet2.gather_points_wrapper(batch, chans, n_pts, npoint, features, idx, out)
+        # a copy: a bf16 payload goes through fp32 and back bit-exactly (xyz, the usual operand, is fp32 anyway)
+        pointnet2.gather_points_wrapper(batch, chans, n_pts, npoint, features.float(), idx, out)
+        out = out.to(features.dtype)
         ctx.save_for_backward(idx)
         ctx.src_shape = (chans, n_pts)
         return out
@@ -115,8 +117,8 @@ class ThreeInterpolate(Function):
         assert features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
         batch, chans, n_known = features.size()
         n_unknown = idx.size(1)
-        out = _new(features, (batch, chans, n_unknown), torch.float32)
-        pointnet2.three_interpolate_wrapper(batch, chans, n_known, n_unknown, features, idx, weight, out)
+        out = _new(features, (batch, chans, n_unknown), features.dtype)     # payload dtype in = payload dtype out
+        pointnet2.three_interpolate_wrapper(batch, chans, n_known, n_unknown, features, idx, weight.float(), out)
         ctx.save_for_backward(idx, weight)
         ctx.n_known = n_known
         return out
@@ -155,7 +157,8 @@ class GroupingOperation(Function):
         batch, npoint, nsample = idx.size()
         _, chans, n_pts = features.size()
         out = _new(features, (batch, chans, npoint, nsample), torch.float32)
-        pointnet2.group_points_wrapper(batch, chans, n_pts, npoint, nsample, features, idx, out)
+        pointnet2.group_points_wrapper(batch, chans, n_pts, npoint, nsample, features.float(), idx, out)   # a copy: exact for bf16
+        out = out.to(features.dtype)
         ctx.save_for_backward(idx)
         ctx.n_pts = n_pts
         return out
@@ -219,7 +222,7 @@ class _FusedQueryGroup(Function):
         batch, n_pts, _ = xyz.size()
         npoint, nsample = idx.size(1), idx.size(2)
         chans = 0 if features is None else features.size(1)
-        out = _new(xyz, (batch, 3 + chans, npoint, nsample), torch.float32)
+        out = _new(xyz, (batch, 3 + chans, npoint, nsample), torch.float32 if features is None else features.dtype)
         pointnet2.query_group_wrapper(batch, chans, n_pts, npoint, nsample, xyz, new_xyz,
                                       None if features is None else features.contiguous(), idx, out)
         ctx.save_for_backward(idx)
@@ -248,9 +251,10 @@ class _FusedQueryGroupProj(Function):
         batch, n_pts, _ = xyz.size()
         npoint, nsample = idx.size(1), idx.size(2)
         chans = zf.size(1)
-        zf, wx = zf.contiguous(), wx.contiguous()
-        rel = _new(xyz, (batch, 3, npoint, nsample), torch.float32)
-        y = _new(xyz, (batch, chans, npoint, nsample), torch.float32)
+        zf, wx = zf.contiguous(), wx.contiguous().float()
+        # rel (relative coordinates) is only read by the backward (d wx): a forward-only call does not write it
+        rel = _new(xyz, (batch, 3, npoint, nsample), zf.dtype) if any(ctx.needs_input_grad) else None
+        y = _new(xyz, (batch, chans, npoint, nsample), zf.dtype)
         pointnet2.query_group_proj_wrapper(batch, chans, n_pts, npoint, nsample, xyz, new_xyz, zf, wx, idx, rel, y)
         ctx.save_for_backward(idx, rel)
         ctx.dims = (chans, n_pts)

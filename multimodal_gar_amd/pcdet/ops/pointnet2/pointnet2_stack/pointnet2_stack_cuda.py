@@ -7,9 +7,17 @@ entries are out of scope: PV-RCNN++ only, unreachable from MGAR-net -- SURVEY.md
 from ..... import _lib as L
 
 
+def _note_pairs(kernel, cnt_a, cnt_b, scans=1):
+    """Instrumented runs only (bench.py's roofline step): sum_i M_i * N_i pair tests of a stacked-layout scan; the counts
+    live on the device, so this syncs -- never on the product path (L.note_pair_tests returns at once when timers are off)."""
+    if L._KT_STATE["on"]:
+        L.note_pair_tests(kernel, scans * float((cnt_a.double() * cnt_b.double()).sum().item()))
+
+
 def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
     L.call("mgar_ball_query_stack", B, M, float(radius), nsample, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt),
            L.fptr(xyz), L.iptr(xyz_batch_cnt), L.iptr(idx), L.stream_of(xyz))
+    _note_pairs("ball_query_kernel", new_xyz_batch_cnt, xyz_batch_cnt)
     return 1
 
 
@@ -20,6 +28,7 @@ def ball_query_multi_wrapper(B, M, radii, nsamples, new_xyz, new_xyz_batch_cnt, 
     fa, ia, pa = L.host_arrays(radii, nsamples, idx_list)
     L.call("mgar_ball_query_multi_stack", B, M, len(radii), fa, ia, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt), L.fptr(xyz),
            L.iptr(xyz_batch_cnt), pa, L.stream_of(xyz))
+    _note_pairs("ball_query_kernel", new_xyz_batch_cnt, xyz_batch_cnt)
     return 1
 
 
@@ -58,11 +67,13 @@ def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, 
     L.call("mgar_three_nn_stack", unknown_batch_cnt.shape[0], unknown.shape[0], known.shape[0], L.fptr(unknown),
            L.iptr(unknown_batch_cnt), L.fptr(known), L.iptr(known_batch_cnt), L.fptr(dist2), L.iptr(idx),
            L.stream_of(unknown))
+    _note_pairs("three_nn_kernel", unknown_batch_cnt, known_batch_cnt)
 
 
 def three_interpolate_wrapper(features, idx, weight, out):
-    L.call("mgar_three_interpolate_stack", idx.shape[0], features.shape[1], L.fptr(features), L.iptr(idx),
-           L.fptr(weight), L.fptr(out), L.stream_of(features))
+    dt = features.dtype        # feature payload: float32 or bfloat16
+    L.payload_call("mgar_three_interpolate_stack", dt, idx.shape[0], features.shape[1], L.pptr(features, dt), L.iptr(idx),
+                   L.fptr(weight), L.pptr(out, dt), L.stream_of(features))
 
 
 def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
@@ -72,9 +83,10 @@ def three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
 
 # ---- fused ops that are torch op chains in the reference (no pybind counterpart) ----
 def query_group_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, idx_raw, out):
-    L.call("mgar_query_group_stack_fwd", B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
-           L.iptr(new_xyz_batch_cnt), L.fptr(features) if features is not None else None, L.iptr(idx_raw), L.fptr(out),
-           L.stream_of(xyz))
+    dt = out.dtype
+    L.payload_call("mgar_query_group_stack_fwd", dt, B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
+                   L.iptr(new_xyz_batch_cnt), L.pptr(features, dt) if features is not None else None, L.iptr(idx_raw),
+                   L.pptr(out, dt), L.stream_of(xyz))
     return 1
 
 
@@ -88,9 +100,11 @@ def query_group_proj_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_
                              zf_ld=None, zf_col=0):
     """zf: (N, zf_ld) matrix whose columns zf_col .. zf_col + C hold this scale's projection."""
     zf_ld = C if zf_ld is None else zf_ld
-    L.call("mgar_query_group_proj_stack_fwd", B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
-           L.iptr(new_xyz_batch_cnt), zf.data_ptr() + 4 * zf_col, zf_ld, L.fptr(wx), L.iptr(idx_raw),
-           L.fptr(rel_out) if rel_out is not None else None, L.fptr(y_out), L.stream_of(xyz))
+    dt = zf.dtype
+    L.pptr(zf, dt)             # device / contiguity / dtype checks; the call below takes the pointer of the column block
+    L.payload_call("mgar_query_group_proj_stack_fwd", dt, B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
+                   L.iptr(new_xyz_batch_cnt), zf.data_ptr() + zf.element_size() * zf_col, zf_ld, L.fptr(wx), L.iptr(idx_raw),
+                   L.pptr(rel_out, dt) if rel_out is not None else None, L.pptr(y_out, dt), L.stream_of(xyz))
     return 1
 
 

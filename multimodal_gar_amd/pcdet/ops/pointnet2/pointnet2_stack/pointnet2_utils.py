@@ -63,8 +63,11 @@ class GroupingOperation(Function):
         n_rows, chans = features.size()
         n_samples = idx_batch_cnt.shape[0]
         out = _empty(features, (n_query, chans, nsample), torch.float32)
-        pointnet2.group_points_wrapper(n_samples, n_query, chans, nsample, features, features_batch_cnt, idx,
+        # the un-fused grouping copies elements: a bf16 payload goes through fp32 and back, bit-exactly (the fused
+        # query-and-group kernels, which carry the traffic, read and write bf16 directly)
+        pointnet2.group_points_wrapper(n_samples, n_query, chans, nsample, features.float(), features_batch_cnt, idx,
                                        idx_batch_cnt, out)
+        out = out.to(features.dtype)
         ctx.save_for_backward(idx, features_batch_cnt, idx_batch_cnt)
         ctx.dims = (n_samples, n_rows)
         return out
@@ -96,7 +99,7 @@ class _FusedQueryGroup(Function):
         idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
         pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
         chans = 0 if features is None else features.shape[1]
-        out = _empty(xyz, (3 + chans, n_query * nsample), torch.float32)
+        out = _empty(xyz, (3 + chans, n_query * nsample), torch.float32 if features is None else features.dtype)
         pointnet2.query_group_wrapper(n_samples, n_query, chans, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                       None if features is None else features.contiguous(), idx, out)
         ctx.save_for_backward(idx, xyz_batch_cnt, new_xyz_batch_cnt)
@@ -127,10 +130,11 @@ class _FusedQueryGroupProj(Function):
         n_query = new_xyz.shape[0]
         idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
         pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
-        zf, wx = zf.contiguous(), wx.contiguous()
+        zf, wx = zf.contiguous(), wx.contiguous().float()
         chans = zf.shape[1]
-        rel = _empty(xyz, (3, n_query * nsample), torch.float32)
-        y = _empty(xyz, (chans, n_query * nsample), torch.float32)
+        # rel (the relative coordinates) is only needed by the backward (d wx): a forward-only call does not write it
+        rel = _empty(xyz, (3, n_query * nsample), zf.dtype) if any(ctx.needs_input_grad) else None
+        y = _empty(xyz, (chans, n_query * nsample), zf.dtype)
         pointnet2.query_group_proj_wrapper(n_samples, n_query, chans, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                            zf, wx, idx, rel, y)
         ctx.save_for_backward(idx, xyz_batch_cnt, new_xyz_batch_cnt, rel)
@@ -182,6 +186,8 @@ class _FusedQueryGroupProjMSG(Function):
             zf = features @ w_f.t()                                                            # (N, ld)
         outs, saved = [], []
         col = 0
+        need_bwd = any(ctx.needs_input_grad)
+        zf = zf.contiguous()
         # One scan per radius here.  (The multi-radius kernel, csrc/ball_query.hip, wins where the rows fill up and
         # the scans stop early -- the trunk's FPS centres: 2.56 vs 3.38 ms; the RoI grid points rarely fill their
         # smallest ball, every scan runs to the end of the cloud and the heavier per-pair path loses: 4.16 vs 3.51 ms.)
@@ -189,13 +195,13 @@ class _FusedQueryGroupProjMSG(Function):
         for radius, nsample, idx in zip(radii, nsamples, idxs):
             pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
         for radius, nsample, w, c, idx in zip(radii, nsamples, ws, chans, idxs):
-            wx = w[:, :3].contiguous()
-            rel = _empty(xyz, (3, n_query * nsample), torch.float32)
-            y = _empty(xyz, (c, n_query * nsample), torch.float32)
+            wx = w[:, :3].contiguous().float()
+            rel = _empty(xyz, (3, n_query * nsample), zf.dtype) if need_bwd else None
+            y = _empty(xyz, (c, n_query * nsample), zf.dtype)
             pointnet2.query_group_proj_wrapper(n_samples, n_query, c, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                                zf, wx, idx, rel, y, zf_ld=ld, zf_col=col)
             outs.append(y)
-            saved += [idx, rel]
+            saved += [idx, rel if rel is not None else idx]
             col += c
         ctx.save_for_backward(xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, *saved)
         ctx.meta = (n_samples, n_query, tuple(chans), tuple(nsamples), tuple(w.shape for w in weights))
@@ -365,7 +371,7 @@ class ThreeInterpolate(Function):
         ctx.save_for_backward(idx, weight)
         ctx.n_known = features.shape[0]
         out = features.new_zeros((idx.shape[0], features.shape[1]))
-        pointnet2.three_interpolate_wrapper(features.contiguous(), idx, weight, out)
+        pointnet2.three_interpolate_wrapper(features.contiguous(), idx, weight.float(), out)
         return out
 
     @staticmethod

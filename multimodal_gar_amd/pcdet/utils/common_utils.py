@@ -19,7 +19,10 @@ def rotate_points_along_z(points, angle):
     cosa, sina = torch.cos(angle), torch.sin(angle)
     zeros, ones = angle.new_zeros(points.shape[0]), angle.new_ones(points.shape[0])
     rot = torch.stack((cosa, sina, zeros, -sina, cosa, zeros, zeros, zeros, ones), dim=1).view(-1, 3, 3).float()
-    out = torch.cat((torch.matmul(points[:, :, 0:3], rot), points[:, :, 3:]), dim=-1)
+    # geometry is fp32 on every configuration: under the bf16 configurations' autocast this matmul would otherwise run in
+    # bf16 and move the RoI grid points (and with them the ball / voxel query indices)
+    with torch.autocast(device_type=points.device.type, enabled=False):
+        out = torch.cat((torch.matmul(points[:, :, 0:3].float(), rot), points[:, :, 3:]), dim=-1)
     return out.numpy() if is_numpy else out
 
 

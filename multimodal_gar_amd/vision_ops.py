@@ -23,13 +23,16 @@ def convert_boxes_to_roi_format(boxes: List[Tensor]) -> Tensor:
 class _RoIAlign(Function):
     @staticmethod
     def forward(ctx, inp, rois, spatial_scale, ph, pw, sampling_ratio, aligned):
-        inp = inp.contiguous().float()
+        inp = inp.contiguous()
+        if inp.dtype != torch.bfloat16:
+            inp = inp.float()
+        dt = inp.dtype                        # feature payload: float32 or bfloat16; boxes stay float32
         rois = rois.contiguous().float()
         n, c, h, w = inp.shape
         k = rois.shape[0]
-        out = torch.empty((k, c, ph, pw), dtype=torch.float32, device=inp.device)
-        L.call("mgar_roi_align_fwd", L.fptr(inp), n, c, h, w, L.fptr(rois), k, ph, pw, float(spatial_scale),
-               int(sampling_ratio), int(bool(aligned)), L.fptr(out), L.stream_of(inp))
+        out = torch.empty((k, c, ph, pw), dtype=dt, device=inp.device)
+        L.payload_call("mgar_roi_align_fwd", dt, L.pptr(inp, dt), n, c, h, w, L.fptr(rois), k, ph, pw, float(spatial_scale),
+                       int(sampling_ratio), int(bool(aligned)), L.pptr(out, dt), L.stream_of(inp))
         ctx.save_for_backward(rois)
         ctx.cfg = (inp.shape, float(spatial_scale), ph, pw, int(sampling_ratio), int(bool(aligned)))
         return out
@@ -42,7 +45,7 @@ class _RoIAlign(Function):
         grad_in = None
         if ctx.needs_input_grad[0]:
             grad_in = torch.zeros((n, c, h, w), dtype=torch.float32, device=grad_out.device)
-            grad_out = grad_out.contiguous()
+            grad_out = grad_out.contiguous().float()
             L.call("mgar_roi_align_bwd", L.fptr(grad_out), n, c, h, w, L.fptr(rois), rois.shape[0], ph, pw,
                    scale, sr, al, L.fptr(grad_in), L.stream_of(grad_out))
         return grad_in, None, None, None, None, None, None

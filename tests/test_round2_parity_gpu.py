@@ -107,14 +107,20 @@ def test_clip_model_voxel_route_train_backward_vs_oracle_backend():
     for i, (a, b) in enumerate(zip(got, want)):
         close(a, b, rtol=2e-3, atol=1e-5, what="output %d" % i)
     gp, cp = dict(gm.named_parameters()), dict(cm.named_parameters())
-    checked = 0
+    gmax = max(p.grad.abs().max().item() for p in cp.values() if p.grad is not None)
+    checked, bad = 0, []
     for n, p in cp.items():
         if p.grad is None:
             assert gp[n].grad is None, n
             continue
-        # train-mode BatchNorm over a handful of actors amplifies fp32 summation-order noise
-        close(gp[n].grad, p.grad, rtol=2e-2, atol=1e-6, what="grad " + n)
+        # train-mode BatchNorm over a handful of actors amplifies fp32 summation-order noise: 2 % of the parameter's own
+        # gradient scale, or -- for gradients that are analytically ~0, e.g. a bias feeding a BatchNorm -- 2e-4 of the
+        # largest gradient in the model
+        err = (gp[n].grad.detach().double().cpu() - p.grad.double()).abs().max().item()
+        if err > 2e-2 * p.grad.abs().max().item() + 1e-6 and err > 2e-4 * gmax:
+            bad.append((n, err, p.grad.abs().max().item()))
         checked += 1
+    assert not bad, "gradient mismatches (name, err, scale), global max %g: %s" % (gmax, bad[:8])
     assert checked > 100
     lidar = [n for n in cp if "LiDAR_backbone.model.roi_head.roi_grid_pool_layers" in n and cp[n].grad is not None]
     assert len(lidar) >= 20, "voxel RoI pooling parameters must receive gradients"
@@ -155,7 +161,7 @@ def test_roi_grid_lift_at_c3_actor_count_vs_oracle():
     close(res["cuda"][0], res["cpu"][0], what="pooled")
     close(res["cuda"][1], res["cpu"][1], rtol=1e-3, what="d features")
     for x, y in zip(res["cuda"][2], res["cpu"][2]):
-        close(x, y, rtol=1e-3, what="d param")
+        close(x, y, rtol=5e-3, what="d param")    # sums over 221 184 columns through two train-mode BatchNorms, fp32 both sides
 
 
 @pytest.mark.parametrize("shape", [(4, 8, 70000), (3, 5, 33, 16), (1, 6, 1023)])
@@ -172,8 +178,12 @@ def test_batchnorm_large_mean_small_std_matches_float64(shape):
         bn.weight.copy_(torch.linspace(0.5, 1.5, c)); bn.bias.copy_(torch.linspace(-0.2, 0.3, c))
     ref = copy.deepcopy(bn).double()
     xr = x.double().requires_grad_(True)
-    yr = torch.relu(ref(xr))
-    cot = torch.linspace(-1, 1, yr.numel(), device="cuda", dtype=torch.float64).view(yr.shape)
+    pre = ref(xr)
+    yr = torch.relu(pre)
+    # x is quantised at 7.6e-4 standard deviations and the fp32 mean is rounded at half of that, so an element whose
+    # pre-activation is within ~1e-3 of zero may sit on either side of the ReLU in fp32 and in fp64 (any fp32 BatchNorm
+    # would do that); such elements get a zero cotangent so that the comparison does not depend on them
+    cot = torch.linspace(-1, 1, yr.numel(), device="cuda", dtype=torch.float64).view(yr.shape) * (pre.detach().abs() > 5e-3)
     (yr * cot).sum().backward()
     xg = x.clone().requires_grad_(True)
     y = bn_ops.bn_act(xg, bn, True)
@@ -188,8 +198,12 @@ def test_batchnorm_large_mean_small_std_matches_float64(shape):
         bn2 = copy.deepcopy(bn); bn2.weight.grad = None
         ref2 = copy.deepcopy(bn).double()
         xr2 = x.double().requires_grad_(True)
-        pr = torch.relu(ref2(xr2)).max(dim=3).values
-        pc = torch.linspace(-1, 1, pr.numel(), device="cuda", dtype=torch.float64).view(pr.shape)
+        pre2 = ref2(xr2)
+        pr = torch.relu(pre2).max(dim=3).values
+        top2 = pre2.detach().topk(2, dim=3).values
+        # no cotangent on groups whose maximum is within rounding of zero or of the runner-up (the arg-max may differ)
+        pc = torch.linspace(-1, 1, pr.numel(), device="cuda", dtype=torch.float64).view(pr.shape) \
+            * ((pr.detach() > 5e-3) & (top2[..., 0] - top2[..., 1] > 5e-3))
         (pr * pc).sum().backward()
         xg2 = x.clone().requires_grad_(True)
         pooled = bn_ops.bn_act_maxpool(xg2, bn2, True)

@@ -15,7 +15,10 @@ read through 4-byte gathers are reported uncorrected and flagged "uncalibrated".
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 # ktimer name (csrc/errors.hip) -> substring of the kernel symbol
 KERNELS = {
@@ -52,7 +55,10 @@ def main():
     out = {"unit": "bytes per launch (HBM-side, FETCH_SIZE [x2 for float4 streaming readers] + WRITE_SIZE, KiB * 1024)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 at config c3",
            "clips_per_gpu": int(sys.argv[3]) if len(sys.argv) > 3 else 8,   # bench.py attaches the figures only to this per-rank batch
-           "per_launch_bytes": {}, "detail": {}}
+           # sha256[:16] of the .hip file each kernel was compiled from at measurement time: bench.py attaches a figure only
+           # while the source is unchanged
+           "per_launch_bytes": {}, "source_sha16": {}, "detail": {}}
+    from multimodal_gar_amd.op_timer import source_sha16
     for k in KERNELS:
         if k not in fetch or k not in write:
             continue
@@ -61,6 +67,7 @@ def main():
         wide = k in WIDE_READERS
         total = (2.0 * f if wide else f) + w
         out["per_launch_bytes"][k] = round(total)
+        out["source_sha16"][k] = source_sha16(k)
         out["detail"][k] = {"launches": fetch[k][1], "fetch_size_bytes_raw": round(f), "write_size_bytes": round(w),
                             "read_correction": "x2 (16 B/lane streaming reads)" if wide else "none (uncalibrated: 4-byte gathers / scalar streams)"}
     json.dump(out, sys.stdout, indent=1)
