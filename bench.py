@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--route", default="pointnet2", choices=["pointnet2", "voxel"])
     ap.add_argument("--no-gat", action="store_true")
+    ap.add_argument("--unfused-voxel-pool", action="store_true",
+                    help="--route voxel only: run the reference-shaped op chain of NeighborVoxelSAModuleMSG on the device instead "
+                         "of the fused csrc/voxel_roi_pool.hip kernels (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -71,7 +74,6 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every kernel from the host instead of replaying forward + backward from a HIP graph "
                          "(torch.cuda.CUDAGraph; default on: 4-9 %% per step, more on ranks that hold a single clip)")
-    ap.add_argument("--require-graph", action="store_true", help="fail instead of falling back to eager launches when capture fails")
     ap.add_argument("--ddp-wrapper", action="store_true",
                     help="eager DistributedDataParallel (bucketed all-reduce overlapped with backward) instead of one flattened "
                          "gradient all-reduce after the backward; implies --no-graph (DDP hooks cannot be captured)")
@@ -126,9 +128,13 @@ def kernel_rooflines(step, batch, frames, n_points, clips_local=None):
     # one stream for this step: with the RGB branch on its side stream two kernels share the chip and the time
     # between a kernel's two events is no longer the time that kernel needs
     overlap, step.module.overlap_branches = step.module.overlap_branches, False
+    # one plain eager step first: the timed steps replayed a graph (private memory pool) and capture()'s warm-up ran on a
+    # side stream, so this stream's caching-allocator pool is cold -- without this every large allocation of the
+    # instrumented step would be a synchronous hipMalloc sitting between an op's two events
+    step.run_eager(batch)
+    torch.cuda.synchronize()
     L.kernel_timers(enable=True)
     L.kernel_timers()                       # drop anything recorded so far
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
     with AtenOpTimer() as lib_ops:
         step.run_eager(batch)
@@ -278,6 +284,12 @@ def main():
     torch.backends.cudnn.benchmark = not args.no_miopen_find   # MIOpen find mode for the I3D convolutions
     log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
     use_graph = not args.no_graph and not args.ddp_wrapper
+    if use_graph and args.route == "voxel":
+        # the voxeliser in front of the voxel route (torch.unique, data-dependent sizes) synchronises the host and cannot be
+        # captured: this route is timed with host-issued launches on one stream
+        log("route voxel: host-issued launches (the voxeliser's data-dependent sizes cannot be captured into a graph)")
+        use_graph = False
+        args.no_graph = True
     if args.mode == "train":
         if args.precision != "fp32":
             raise SystemExit("bench.py: the backward runs in fp32 only (bf16 is a forward configuration: c2 / c5)")
@@ -285,6 +297,11 @@ def main():
                            manual_allreduce=not args.ddp_wrapper)
     else:
         step = W.ForwardStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, precision=args.precision)
+    if args.unfused_voxel_pool:
+        from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack.voxel_pool_modules import NeighborVoxelSAModuleMSG
+        for m in step.module.modules():
+            if isinstance(m, NeighborVoxelSAModuleMSG):
+                m.fused = False
     # frozen I3D on a side stream (no autograd there: DDP-safe).  Only together with the HIP graph: issued eagerly from
     # the host the two-stream step measured 362 ms against 269 ms on one stream (and 257 ms as a graph on two).
     step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
@@ -304,12 +321,10 @@ def main():
             step.capture(batch)
             log("forward + backward captured into a HIP graph")
         except RuntimeError as e:   # what torch raises for an op that cannot be captured / a failed HIP call during capture
-            if args.require_graph:
-                raise
-            step.graph = None
-            step.module.overlap_branches = False
-            log("HIP-graph capture failed (%s: %s); continuing with eager launches" % (type(e).__name__, str(e).splitlines()[0][:200]))
-            torch.cuda.synchronize()
+            # a failed capture leaves the device RNG in capture mode: nothing after it can be trusted, so this is fatal
+            # (run with --no-graph to time host-issued launches)
+            raise SystemExit("bench.py: HIP-graph capture failed (%s: %s); rerun with --no-graph"
+                             % (type(e).__name__, str(e).splitlines()[0][:200]))
     for i in range(args.warmup):
         step.run(batch); torch.cuda.synchronize(); log("warmup step %d done" % i)
     barrier()

@@ -366,6 +366,34 @@ int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr, const int *col,
                    const float *xr, const float *att, float slope, const float *edge_scale, const float *alpha,
                    const float *grad_out, float *grad_xl, float *grad_xr, float *grad_att, void *stream);
 
+/* ===================== fused Voxel-RoI pooling ====================
+ * One scale of NeighborVoxelSAModuleMSG between mlps_in and mlps_out
+ * (pcdet/ops/pointnet2/pointnet2_stack/voxel_pool_modules.py:86-126; queries from voxel_query_gpu.cu:10-89):
+ *     pooled[c, m] = max_s relu( feats[idx[m,s], c] + BN_pos( w_pos[c] . (xyz[idx[m,s]] - new_xyz[m]) ) )
+ * idx (M, nsample) is the RAW output of mgar_voxel_query_stack (GLOBAL voxel rows; idx[m][0] == -1 marks an empty
+ * neighbourhood, whose features and relative coordinates are zero as in the reference, :101,:106).  feats (N, ld_f) is the
+ * row-major output of mlps_in on all voxels; pooled / arg are CHANNEL-MAJOR (C, M) (what mlps_out's Conv1d consumes);
+ * 1 <= C <= 32.  BN_pos is the module's BatchNorm2d(C) after the bias-free Conv2d(3, C): in training mode its batch
+ * statistics over all M*nsample columns come from mgar_voxel_roi_pool_stats (the position branch is linear in the
+ * relative coordinates, so first and second moments of those suffice): moments[10] doubles = E[r] (3), Cov(r) (6: xx, xy,
+ * xz, yy, yz, zz), n; mean / invstd (C) feed _fwd and _bwd; running statistics get the usual momentum update.
+ * bwd: dfeats (N, ld_f) is ACCUMULATED into (caller zero-fills; may be NULL), dgamma / dbeta (C) and dw_pos (C, 3) are
+ * written; train_stats = 0 treats mean / invstd as constants (eval-mode BatchNorm). */
+long long mgar_voxel_roi_pool_stats_workspace_doubles(int M, int nsample);
+long long mgar_voxel_roi_pool_bwd_workspace_floats(int M, int C);
+int mgar_voxel_roi_pool_stats(int M, int nsample, int C, const float *xyz, const float *new_xyz, const int *idx,
+                              const float *w_pos, float eps, float momentum, double *workspace, double *moments,
+                              float *mean, float *invstd, float *running_mean, float *running_var,
+                              long long *num_batches_tracked, void *stream);
+int mgar_voxel_roi_pool_fwd(int M, int nsample, int C, const float *xyz, const float *new_xyz, const float *feats,
+                            int ld_f, const int *idx, const float *w_pos, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, float *pooled, unsigned char *arg, void *stream);
+int mgar_voxel_roi_pool_bwd(int M, int nsample, int C, const float *xyz, const float *new_xyz, const int *idx,
+                            const float *w_pos, const float *mean, const float *invstd, const float *gamma,
+                            const double *moments, int train_stats, const float *dpooled, const float *pooled,
+                            const unsigned char *arg, float *workspace, float *dfeats, int ld_f, float *dgamma,
+                            float *dbeta, float *dw_pos, void *stream);
+
 /* ============================ bf16 feature payloads (BASELINE configs c2, c5) ============================
  * The reference's kernels are fp32 + int32 only.  For the bf16 configurations SURVEY.md section 8 keeps coordinates,
  * distances, indices and BatchNorm statistics in fp32 / int32 and stores only FEATURE PAYLOADS (and runs the GEMMs) in
@@ -429,6 +457,10 @@ int mgar_maxpool3d_same_fwd_bf16(const void *x, int NC, int T, int H, int W, int
 int mgar_roi_align_fwd_bf16(const void *input, int N, int C, int H, int W, const float *rois, int K,
                             int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
                             void *out, void *stream);
+/* feats, pooled */
+int mgar_voxel_roi_pool_fwd_bf16(int M, int nsample, int C, const float *xyz, const float *new_xyz, const void *feats,
+                                 int ld_f, const int *idx, const float *w_pos, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, void *pooled, unsigned char *arg, void *stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -78,13 +78,18 @@ _PROTOS = {
     "mgar_dafm_attn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P],
     "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_voxel_roi_pool_stats_workspace_doubles": [_I, _I],
+    "mgar_voxel_roi_pool_bwd_workspace_floats": [_I, _I],
+    "mgar_voxel_roi_pool_stats": [_I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_voxel_roi_pool_fwd": [_I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_voxel_roi_pool_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P],
 }
 # bf16-payload twins (include/mgar_ops.h, last section): identical argument lists
 for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_query_group_proj_batch_fwd",
            "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
            "mgar_bn_act_fwd_grouped", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
            "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_stack",
-           "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd"):
+           "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]
 BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 
@@ -92,7 +97,7 @@ _fns = {}
 for _name, _args in _PROTOS.items():
     _fn = getattr(_cdll, _name)  # AttributeError here = the library is stale: rebuild it
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_int
+    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats")) else ctypes.c_int
     _fns[_name] = _fn
 
 _cdll.mgar_abi_version.restype = ctypes.c_int

@@ -125,3 +125,35 @@ def rowmajor_dw(a, f):
     ws = torch.empty((max(1, L.raw("mgar_rowmajor_dw_workspace_floats", n, co, ci)),), dtype=torch.float32, device=a.device)
     L.call("mgar_rowmajor_dw", L.fptr(a), co, L.fptr(f), ci, n, co, ci, L.fptr(ws), L.fptr(dw), L.stream_of(a))
     return dw
+
+
+# ---- fused Voxel-RoI pooling (csrc/voxel_roi_pool.hip; no pybind counterpart: a torch op chain in the reference) ----
+def voxel_roi_pool_stats(M, nsample, C, xyz, new_xyz, idx_raw, w_pos, eps, momentum, moments, mean, invstd, running_mean,
+                         running_var, num_batches_tracked):
+    import torch
+    ws = torch.empty((max(1, L.raw("mgar_voxel_roi_pool_stats_workspace_doubles", M, nsample)),), dtype=torch.float64, device=xyz.device)
+    L.call("mgar_voxel_roi_pool_stats", M, nsample, C, L.fptr(xyz), L.fptr(new_xyz), L.iptr(idx_raw), L.fptr(w_pos), float(eps),
+           float(momentum), L.dev_ptr(ws, torch.float64), L.dev_ptr(moments, torch.float64), L.fptr(mean), L.fptr(invstd),
+           L.fptr(running_mean) if running_mean is not None else None, L.fptr(running_var) if running_var is not None else None,
+           L.dev_ptr(num_batches_tracked, torch.int64) if num_batches_tracked is not None else None, L.stream_of(xyz))
+    return 1
+
+
+def voxel_roi_pool_fwd(M, nsample, C, xyz, new_xyz, feats, idx_raw, w_pos, mean, invstd, gamma, beta, pooled, arg):
+    import torch
+    dt = feats.dtype           # payload of feats / pooled: float32 or bfloat16
+    L.payload_call("mgar_voxel_roi_pool_fwd", dt, M, nsample, C, L.fptr(xyz), L.fptr(new_xyz), L.pptr(feats, dt), feats.shape[1],
+                   L.iptr(idx_raw), L.fptr(w_pos), L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), L.pptr(pooled, dt),
+                   L.dev_ptr(arg, torch.uint8), L.stream_of(xyz))
+    return 1
+
+
+def voxel_roi_pool_bwd(M, nsample, C, xyz, new_xyz, idx_raw, w_pos, mean, invstd, gamma, moments, train_stats, dpooled, pooled, arg,
+                       dfeats, dgamma, dbeta, dw_pos):
+    import torch
+    ws = torch.empty((max(1, L.raw("mgar_voxel_roi_pool_bwd_workspace_floats", M, C)),), dtype=torch.float32, device=xyz.device)
+    L.call("mgar_voxel_roi_pool_bwd", M, nsample, C, L.fptr(xyz), L.fptr(new_xyz), L.iptr(idx_raw), L.fptr(w_pos), L.fptr(mean),
+           L.fptr(invstd), L.fptr(gamma), L.dev_ptr(moments, torch.float64) if moments is not None else None, int(train_stats),
+           L.fptr(dpooled), L.fptr(pooled), L.dev_ptr(arg, torch.uint8), L.fptr(ws), L.fptr(dfeats) if dfeats is not None else None,
+           dfeats.shape[1] if dfeats is not None else C, L.fptr(dgamma), L.fptr(dbeta), L.fptr(dw_pos), L.stream_of(xyz))
+    return 1

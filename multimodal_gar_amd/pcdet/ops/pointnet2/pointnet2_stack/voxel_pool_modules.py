@@ -9,8 +9,58 @@ from typing import List
 import torch
 import torch.nn as nn
 
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import pointnet2_stack_cuda as pointnet2
 from . import voxel_query_utils
 from .....nn_utils import PointwiseSequential
+
+
+class _FusedVoxelRoIPool(Function):
+    """pooled (C, M) = max_s relu(feats[idx[m, s]] + BN_pos(w_pos . rel_xyz)) on csrc/voxel_roi_pool.hip: everything
+    between mlps_in and mlps_out of one scale (reference voxel_pool_modules.py:94-117) without any (C, M, nsample) tensor."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, idx_raw, w_pos, gamma, beta, bn):
+        n_query, nsample = idx_raw.shape
+        chans = feats.shape[1]
+        xyz, new_xyz, feats = xyz.contiguous(), new_xyz.contiguous(), feats.contiguous()
+        w_pos, gamma, beta = w_pos.contiguous().float(), gamma.float(), beta.float()
+        dev = xyz.device
+        train_stats = bn.training or not bn.track_running_stats
+        moments = None
+        if train_stats:
+            mean = torch.empty((chans,), dtype=torch.float32, device=dev)
+            invstd = torch.empty_like(mean)
+            moments = torch.empty((10,), dtype=torch.float64, device=dev)
+            track = bn.track_running_stats and bn.running_mean is not None
+            pointnet2.voxel_roi_pool_stats(n_query, nsample, chans, xyz, new_xyz, idx_raw, w_pos, bn.eps,
+                                           bn.momentum if bn.momentum is not None else 0.1, moments, mean, invstd,
+                                           bn.running_mean if track else None, bn.running_var if track else None,
+                                           bn.num_batches_tracked if track else None)
+        else:
+            mean, invstd = bn.running_mean.float(), torch.rsqrt(bn.running_var.float() + bn.eps)
+        pooled = torch.empty((chans, n_query), dtype=feats.dtype, device=dev)
+        arg = torch.empty((chans, n_query), dtype=torch.uint8, device=dev)
+        pointnet2.voxel_roi_pool_fwd(n_query, nsample, chans, xyz, new_xyz, feats, idx_raw, w_pos, mean, invstd, gamma, beta, pooled, arg)
+        ctx.save_for_backward(xyz, new_xyz, idx_raw, w_pos, mean, invstd, gamma, moments, pooled, arg)
+        ctx.meta = (feats.shape, train_stats)
+        ctx.mark_non_differentiable(arg)
+        return pooled, arg
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpooled, darg=None):
+        xyz, new_xyz, idx_raw, w_pos, mean, invstd, gamma, moments, pooled, arg = ctx.saved_tensors
+        (n_rows, chans), train_stats = ctx.meta
+        n_query, nsample = idx_raw.shape
+        dfeats = torch.zeros((n_rows, chans), dtype=torch.float32, device=xyz.device) if ctx.needs_input_grad[2] else None
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        dw = torch.empty_like(w_pos)
+        pointnet2.voxel_roi_pool_bwd(n_query, nsample, chans, xyz, new_xyz, idx_raw, w_pos, mean, invstd, gamma, moments, train_stats,
+                                     dpooled.contiguous().float(), pooled.float(), arg, dfeats, dgamma, dbeta, dw)
+        return None, None, dfeats, None, dw, dgamma, dbeta, None
 
 
 class NeighborVoxelSAModuleMSG(nn.Module):
@@ -32,6 +82,7 @@ class NeighborVoxelSAModuleMSG(nn.Module):
                                                nn.BatchNorm1d(spec[2]), nn.ReLU()))
         self.relu = nn.ReLU()
         self.pool_method = pool_method
+        self.fused = True      # device path: csrc/voxel_roi_pool.hip (set False to run the un-fused op chain on the device)
         self.init_weights()
 
     def init_weights(self):
@@ -53,6 +104,19 @@ class NeighborVoxelSAModuleMSG(nn.Module):
         for k, grouper in enumerate(self.groupers):
             feats_in = self.mlps_in[k](features.permute(1, 0).unsqueeze(0))        # (1, C, N)
             feats_in = feats_in.squeeze(0).permute(1, 0).contiguous()              # (N, C)
+            pos_conv, pos_bn = self.mlps_pos[k][0], self.mlps_pos[k][1]
+            if (self.fused and xyz.is_cuda and self.pool_method == 'max_pool' and feats_in.shape[1] <= 32 and pos_conv.bias is None
+                    and not (torch.is_grad_enabled() and feats_in.dtype != torch.float32)):
+                # device path: voxel query, then ONE kernel for group + position MLP + BatchNorm + ReLU + max
+                # (csrc/voxel_roi_pool.hip); the CPU run below is the reference's op chain
+                idx_raw = voxel_query_utils.voxel_query_raw(grouper.max_range, grouper.radius, grouper.nsample, xyz, new_xyz,
+                                                            new_coords, voxel2point_indices)
+                gamma = pos_bn.weight if pos_bn.affine else torch.ones(feats_in.shape[1], device=xyz.device)
+                beta = pos_bn.bias if pos_bn.affine else torch.zeros(feats_in.shape[1], device=xyz.device)
+                pooled, _ = _FusedVoxelRoIPool.apply(xyz, new_xyz, feats_in, idx_raw, pos_conv.weight.view(feats_in.shape[1], 3),
+                                                     gamma, beta, pos_bn)                     # (C, M) channel-major
+                per_scale.append(self.mlps_out[k](pooled.unsqueeze(0)).squeeze(0).permute(1, 0))
+                continue
             grouped, grouped_xyz, empty = grouper(new_coords, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                                   feats_in, voxel2point_indices)
             keep = (~empty).view(-1, 1, 1).to(grouped.dtype)

@@ -41,6 +41,19 @@ class VoxelQuery(Function):
 voxel_query = VoxelQuery.apply
 
 
+def voxel_query_raw(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices):
+    """The kernel's own output: idx (M, nsample) int32 GLOBAL voxel rows with idx[m, 0] == -1 for an empty neighbourhood
+    (voxel_query_gpu.cu:10-89), without the mask / zero-fill post-processing of VoxelQuery -- what the fused pooling
+    kernel consumes."""
+    n_query = new_coords.shape[0]
+    _, gz, gy, gx = point_indices.shape
+    idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
+    z_range, y_range, x_range = max_range
+    pointnet2.voxel_query_wrapper(n_query, gz, gy, gx, nsample, radius, z_range, y_range, x_range, new_xyz.contiguous(),
+                                  xyz.contiguous(), new_coords.contiguous(), point_indices.contiguous(), idx)
+    return idx
+
+
 class VoxelQueryAndGrouping(nn.Module):
     """voxel_query -> make indices sample-local -> group xyz and features.
     Returns (grouped_features (M, C, nsample), grouped_xyz (M, 3, nsample), empty_ball_mask).
