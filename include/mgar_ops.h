@@ -146,6 +146,15 @@ int mgar_voxel_query_stack(int M, int R1, int R2, int R3, int nsample, float rad
                            const float *new_xyz, const float *xyz, const int *new_coords,
                            const int *point_indices, int *idx, void *stream);
 
+/* The same query with the voxel -> row lookups served by the hash table of mgar_voxel_hash_build (below) instead of the
+ * dense (B, R1, R2, R3) table of generate_voxel2pinds (pcdet/utils/common_utils.py:244-252; 80 MB per sample at the
+ * shipped grid): same cells in the same order, identical idx. */
+int mgar_voxel_query_hash_stack(int M, int R1, int R2, int R3, int nsample, float radius,
+                                int z_range, int y_range, int x_range,
+                                const float *new_xyz, const float *xyz, const int *new_coords,
+                                const long long *table_keys, const int *table_vals, int capacity, int *idx,
+                                void *stream);
+
 /* stack_farthest_point_sampling_wrapper   pointnet2_stack/src/pointnet2_api.cpp:17
  * kernel               pointnet2_stack/src/sampling_gpu.cu:188-319 (always 1024 threads)
  * points (N,3), temp (N), xyz_batch_cnt (batch_size), num_sampled_points (batch_size)
@@ -393,6 +402,36 @@ int mgar_voxel_roi_pool_bwd(int M, int nsample, int C, const float *xyz, const f
                             const double *moments, int train_stats, const float *dpooled, const float *pooled,
                             const unsigned char *arg, float *workspace, float *dfeats, int ld_f, float *dgamma,
                             float *dbeta, float *dw_pos, void *stream);
+
+/* ============ sparse 3-D convolution: trunk of Voxel R-CNN ====================
+ * Replaces the third-party spconv calls of pcdet/models/backbones_3d/spconv_backbone.py:69-170 (SubMConv3d /
+ * SparseConv3d) and the dense voxel -> row table of pcdet/utils/common_utils.py:235-252 as a lookup structure.
+ * Voxel coordinates are (N, 4) int32 [b, z, y, x].
+ *
+ * Hash table: table_keys (capacity) int64 pre-filled with -1, table_vals (capacity) int32 pre-filled with INT_MAX by the
+ * caller; capacity a power of two >= 2 N.  _lookup writes the row stored for each coordinate or -1. */
+int mgar_voxel_hash_build(int N, const int *coords, int Z, int Y, int X, long long *table_keys, int *table_vals,
+                          int capacity, void *stream);
+int mgar_voxel_hash_lookup(int M, const int *coords, int Z, int Y, int X, const long long *table_keys,
+                           const int *table_vals, int capacity, int *rows, void *stream);
+/* Rulebook of one convolution.  geom: 15 HOST ints {kz,ky,kx, sz,sy,sx, pz,py,px, Zi,Yi,Xi, Zo,Yo,Xo}; K = kz*ky*kx
+ * offsets in z-major order (the order of spconv's (C_out, kz, ky, kx, C_in) weight).
+ *   inverse = 0: site_coords = OUTPUT sites, table = hash of the INPUT sites -> nbr (n_sites, K): input row at
+ *                o * stride - pad + k, or -1;
+ *   inverse = 1: site_coords = INPUT sites, table = hash of the OUTPUT sites -> nbr (n_sites, K): output row reached
+ *                through offset k, or -1 (the data gradient gathers over this table). */
+int mgar_spconv_rulebook(int n_sites, const int *site_coords, const int *geom, const long long *table_keys,
+                         const int *table_vals, int capacity, int inverse, int *nbr, void *stream);
+/* out (No, Cout) = sum_k in[nbr[:, k]] . w[k], w (K, Cin, Cout) row-major, fp32 on the exact-fp32 MFMA; rows with
+ * nbr == -1 contribute nothing; out is fully written.  flip_k != 0 reads w[K-1-k] (data gradient of a submanifold
+ * convolution over its own forward table).  Cin, Cout <= 128 (MGAR_EUNSUPPORTED otherwise). */
+int mgar_spconv_gather_gemm(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *w,
+                            int flip_k, float *out, void *stream);
+/* Weight gradient: partial (mgar_spconv_dw_chunks(No), K, Cin, Cout) is written; dW = its sum over the first axis
+ * (left to the caller: a fixed-order reduction, reproducible). */
+int mgar_spconv_dw_chunks(int No);
+int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *dout,
+                   float *partial, void *stream);
 
 /* ============================ bf16 feature payloads (BASELINE configs c2, c5) ============================
  * The reference's kernels are fp32 + int32 only.  For the bf16 configurations SURVEY.md section 8 keeps coordinates,

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -39,6 +39,7 @@ _PROTOS = {
     "mgar_three_interpolate_grad_sorted_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_ball_query_stack": [_I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_query_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_voxel_query_hash_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "mgar_fps_stack": [_I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_group_points_stack": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_group_points_grad_stack": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
@@ -78,6 +79,12 @@ _PROTOS = {
     "mgar_dafm_attn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P],
     "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_voxel_hash_build": [_I, _P, _I, _I, _I, _P, _P, _I, _P],
+    "mgar_voxel_hash_lookup": [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P],
+    "mgar_spconv_rulebook": [_I, _P, _P, _P, _P, _I, _I, _P, _P],
+    "mgar_spconv_gather_gemm": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
+    "mgar_spconv_dw_chunks": [_I],
+    "mgar_spconv_dw": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_voxel_roi_pool_stats_workspace_doubles": [_I, _I],
     "mgar_voxel_roi_pool_bwd_workspace_floats": [_I, _I],
     "mgar_voxel_roi_pool_stats": [_I, _I, _I, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P],

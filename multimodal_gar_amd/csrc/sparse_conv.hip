@@ -1,0 +1,359 @@
+// sparse_conv.hip -- sparse 3-D convolution (submanifold and strided) for gfx950: voxel hash table, rulebook
+// (neighbour tables) built on the device, gather-GEMM forward / data-gradient and weight-gradient kernels on the
+// exact-fp32 MFMA.
+//
+// Replaces the third-party spconv 2.2.3 calls of the reference's Voxel R-CNN trunk
+//   pcdet/models/backbones_3d/spconv_backbone.py:69-170  VoxelBackBone8x
+//       spconv.SubMConv3d(C_in, C_out, 3, padding=1, bias=False, indice_key=...)            (submanifold)
+//       spconv.SparseConv3d(C_in, C_out, k, stride=s, padding=p, bias=False, indice_key=...) (strided)
+// and the dense (B, Z, Y, X) voxel -> row table of pcdet/utils/common_utils.py:235-252 (80 MB per sample at the shipped
+// grid) as a lookup structure.  spconv is not vendored and its CUDA source is not in the reference tree; the
+// arithmetic follows the published definition of the two layers (Graham et al. 2018):
+//   out[o] = sum_k W_k . in[i]  over the kernel offsets k whose input site i = o * stride - pad + k is ACTIVE;
+//   submanifold: output sites = input sites;  strided: output sites = every o with at least one active input.
+//
+// Data structures
+//   * hash table: open addressing, linear probing, 64-bit keys ((b*Z + z)*Y + y)*X + x -> row id, capacity a power of two
+//     >= 2N (load <= 0.5).  Built with one 64-bit atomicCAS per site.
+//   * rulebook = neighbour table nbr (N_out, K) int32: row of the input site under kernel offset k, or -1.  The inverse
+//     table (N_in, K): output row that input i reaches through offset k -- the data gradient is the same gather-GEMM over
+//     it with W_k transposed.
+// Kernels (all features row-major (rows, C), fp32; the MFMA is v_mfma_f32_32x32x2_f32: a k-ordered fp32 FMA chain):
+//   * spconv_gather_gemm_kernel: a workgroup owns 64 output rows; per kernel offset it stages the gathered input rows
+//     (64 x C_in, coalesced along the channels) and W_k (C_in x C_out) in LDS and accumulates 32x32 output blocks; offsets
+//     no row of the tile uses are skipped (most of the 27 at LiDAR sparsity);
+//   * spconv_dw_kernel: grid (site chunks, K); dW_k = A_k^T dOut accumulated in registers over the chunk, written as a
+//     partial (summed by the caller in a fixed order: reproducible).
+#include "common.hpp"
+#include "voxel_hash.hpp"
+
+namespace mgar {
+
+typedef float __attribute__((ext_vector_type(16))) f32x16;
+
+__global__ __launch_bounds__(256) void sph_build_kernel(int N, const int *__restrict__ coords, int Z, int Y, int X,
+                                                        long long *__restrict__ tkeys, int *__restrict__ tvals, int mask) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const long long key = sph_key(coords[i * 4], coords[i * 4 + 1], coords[i * 4 + 2], coords[i * 4 + 3], Z, Y, X);
+    if (key == SPH_EMPTY) return;
+    unsigned slot = (unsigned)sph_mix((unsigned long long)key) & (unsigned)mask;
+    for (int probe = 0; probe <= mask; ++probe) {
+        const long long old = (long long)atomicCAS((unsigned long long *)&tkeys[slot], (unsigned long long)SPH_EMPTY,
+                                                   (unsigned long long)key);
+        if (old == SPH_EMPTY || old == key) {
+            atomicMin(&tvals[slot], i);               // values pre-filled with INT_MAX; duplicate coordinates: smallest row wins
+            return;
+        }
+        slot = (slot + 1) & (unsigned)mask;
+    }
+}
+
+__global__ __launch_bounds__(256) void sph_lookup_kernel(int M, const int *__restrict__ coords, int Z, int Y, int X,
+                                                         const long long *__restrict__ tkeys, const int *__restrict__ tvals,
+                                                         int mask, int *__restrict__ rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const long long key = sph_key(coords[i * 4], coords[i * 4 + 1], coords[i * 4 + 2], coords[i * 4 + 3], Z, Y, X);
+    rows[i] = key == SPH_EMPTY ? -1 : sph_find(tkeys, tvals, mask, key);
+}
+
+struct SpGeom {
+    int kz, ky, kx, sz, sy, sx, pz, py, px;   // kernel, stride, padding (z, y, x)
+    int Zi, Yi, Xi, Zo, Yo, Xo;               // spatial shapes of the input / output grids
+};
+
+// forward rulebook: nbr[o][k] = input row at o * stride - pad + k (table = hash of the INPUT sites)
+__global__ __launch_bounds__(256) void sp_neighbors_kernel(long long total, int K, const int *__restrict__ out_coords, SpGeom g,
+                                                           const long long *__restrict__ tkeys, const int *__restrict__ tvals,
+                                                           int mask, int *__restrict__ nbr) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long o = e / K;
+    const int k = (int)(e - o * K);
+    const int kx = k % g.kx, ky = (k / g.kx) % g.ky, kz = k / (g.kx * g.ky);
+    const int *c = out_coords + o * 4;
+    const long long key = sph_key(c[0], c[1] * g.sz - g.pz + kz, c[2] * g.sy - g.py + ky, c[3] * g.sx - g.px + kx, g.Zi, g.Yi, g.Xi);
+    nbr[e] = key == SPH_EMPTY ? -1 : sph_find(tkeys, tvals, mask, key);
+}
+
+// inverse rulebook: inv[i][k] = output row o with o * stride - pad + k == i (table = hash of the OUTPUT sites)
+__global__ __launch_bounds__(256) void sp_neighbors_inverse_kernel(long long total, int K, const int *__restrict__ in_coords, SpGeom g,
+                                                                   const long long *__restrict__ tkeys,
+                                                                   const int *__restrict__ tvals, int mask, int *__restrict__ inv) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long i = e / K;
+    const int k = (int)(e - i * K);
+    const int kx = k % g.kx, ky = (k / g.kx) % g.ky, kz = k / (g.kx * g.ky);
+    const int *c = in_coords + i * 4;
+    const int nz = c[1] + g.pz - kz, ny = c[2] + g.py - ky, nx = c[3] + g.px - kx;
+    int r = -1;
+    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % g.sz == 0 && ny % g.sy == 0 && nx % g.sx == 0) {
+        const long long key = sph_key(c[0], nz / g.sz, ny / g.sy, nx / g.sx, g.Zo, g.Yo, g.Xo);
+        if (key != SPH_EMPTY) r = sph_find(tkeys, tvals, mask, key);
+    }
+    inv[e] = r;
+}
+
+// ---- gather-GEMM: out[o, :] = sum_k in[nbr[o, k], :] . W[k]  (W (K, Cin, Cout) row-major) ------------------------------
+constexpr int SC_ROWS = 64;       // output rows per workgroup
+constexpr int SC_MAXC = 128;      // C_in, C_out <= 128
+
+// grid ceil(No / 64).  LDS: nbr tile [64][K] ints, A [64][Cin + 1], W [Cin][CoutP] (CoutP = C_out rounded up to 32)
+__global__ __launch_bounds__(256) void spconv_gather_gemm_kernel(int No, int K, int Cin, int Cout, const float *__restrict__ in,
+                                                                 const int *__restrict__ nbr, const float *__restrict__ w,
+                                                                 int flip_k, float *__restrict__ out) {
+    extern __shared__ float lds[];
+    const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 1) & ~1, ALD = CinP + 1;
+    int *nb = reinterpret_cast<int *>(lds);               // [SC_ROWS][K]
+    float *A = lds + SC_ROWS * K;                          // [SC_ROWS][ALD]
+    float *W = A + SC_ROWS * ALD;                          // [CinP][CoutP]
+    __shared__ int used[343];                              // used[k] != 0: some row of this tile has a neighbour under offset k
+    const int o0 = blockIdx.x * SC_ROWS;
+    const int nrow = min(SC_ROWS, No - o0);
+    for (int k = threadIdx.x; k < K; k += 256) used[k] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < SC_ROWS * K; e += 256) {
+        const int r = e / K;
+        const int j = r < nrow ? nbr[(size_t)(o0 + r) * K + (e - r * K)] : -1;
+        nb[e] = j;
+        if (j >= 0) used[e - r * K] = 1;                   // benign race: every writer stores 1
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int sb = wave & 1;                               // which 32-row half of the tile this wave accumulates
+    const int ncb = CoutP / 32;                            // 32-column blocks of the output; this wave: cb = wave>>1, +2, ...
+    f32x16 acc[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        if (!used[k]) continue;                            // uniform over the workgroup (read-only after the barrier above)
+        for (int e = threadIdx.x; e < SC_ROWS * CinP; e += 256) {          // gathered rows, lanes along the channels
+            const int r = e / CinP, c = e - r * CinP;
+            const int j = nb[r * K + k];
+            A[r * ALD + c] = (j >= 0 && c < Cin) ? in[(size_t)j * Cin + c] : 0.f;
+        }
+        const float *wk = w + (size_t)(flip_k ? K - 1 - k : k) * Cin * Cout;
+        for (int e = threadIdx.x; e < CinP * CoutP; e += 256) {
+            const int ci = e / CoutP, co = e - ci * CoutP;
+            W[e] = (ci < Cin && co < Cout) ? wk[(size_t)ci * Cout + co] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {                      // static accumulator indices: no scratch
+            const int cb = (wave >> 1) + 2 * a;
+            if (cb < ncb) {
+                for (int s = 0; s < CinP / 2; ++s) {
+                    const float av = A[(sb * 32 + l) * ALD + 2 * s + h];
+                    const float bv = W[(2 * s + h) * CoutP + cb * 32 + l];
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int cb = (wave >> 1) + 2 * a;
+        const int co = cb * 32 + l;
+        if (cb < ncb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // D[row][col = l]
+                if (row < nrow && co < Cout) out[(size_t)(o0 + row) * Cout + co] = acc[a][r];
+            }
+        }
+    }
+}
+
+// ---- weight gradient: dW[k] (Cin, Cout) = sum_o in[nbr[o, k], :]^T dout[o, :] ----------------------------------------------
+// grid (nchunk, K); partial[(chunk * K + k)][Cin][Cout]; chunk = SC_DW_CHUNK output rows
+constexpr int SC_DW_CHUNK = 8192;
+
+__global__ __launch_bounds__(256) void spconv_dw_kernel(int No, int K, int Cin, int Cout, const float *__restrict__ in,
+                                                        const int *__restrict__ nbr, const float *__restrict__ dout,
+                                                        float *__restrict__ partial) {
+    extern __shared__ float lds[];
+    const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 31) & ~31;
+    float *A = lds;                                   // [SC_ROWS][CinP + 1]   gathered input rows (zero where no neighbour)
+    float *G = A + SC_ROWS * (CinP + 1);              // [SC_ROWS][CoutP + 1]  dout rows
+    __shared__ int nbk[SC_ROWS];
+    __shared__ int any_flag[2];                        // alternating between tiles: a reader of tile t never meets the reset of t + 1
+    const int k = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int nib = CinP / 32, ncb = CoutP / 32, nblk = nib * ncb;     // 32x32 blocks of dW_k; wave w owns blocks w, w+4, ...
+    f32x16 acc[4];                                                      // nblk <= 16 -> at most 4 per wave
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const int row0 = blockIdx.x * SC_DW_CHUNK, row1 = min(No, row0 + SC_DW_CHUNK);
+    int par = 0;
+    for (int t0 = row0; t0 < row1; t0 += SC_ROWS, par ^= 1) {
+        const int nrow = min(SC_ROWS, row1 - t0);
+        if (threadIdx.x == 0) any_flag[par] = 0;
+        __syncthreads();
+        if (threadIdx.x < SC_ROWS) {
+            const int j = threadIdx.x < nrow ? nbr[(size_t)(t0 + threadIdx.x) * K + k] : -1;
+            nbk[threadIdx.x] = j;
+            if (j >= 0) any_flag[par] = 1;
+        }
+        __syncthreads();
+        if (!any_flag[par]) continue;
+        for (int e = threadIdx.x; e < SC_ROWS * CinP; e += 256) {
+            const int r = e / CinP, c = e - r * CinP;
+            const int j = nbk[r];
+            A[r * (CinP + 1) + c] = (j >= 0 && c < Cin) ? in[(size_t)j * Cin + c] : 0.f;
+        }
+        for (int e = threadIdx.x; e < SC_ROWS * CoutP; e += 256) {
+            const int r = e / CoutP, c = e - r * CoutP;
+            G[r * (CoutP + 1) + c] = (r < nrow && c < Cout && nbk[r] >= 0) ? dout[(size_t)(t0 + r) * Cout + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                    // static accumulator indices: no scratch
+            const int blk = wave + 4 * a;
+            if (blk < nblk) {
+                const int ib = blk / ncb, cb = blk - ib * ncb;
+#pragma unroll 4
+                for (int s = 0; s < SC_ROWS / 2; ++s) {  // reduction over the 64 rows of the tile, 2 per MFMA
+                    const float av = A[(2 * s + h) * (CinP + 1) + ib * 32 + l];      // A^T: row = ci, k = site
+                    const float bv = G[(2 * s + h) * (CoutP + 1) + cb * 32 + l];
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+                }
+            }
+        }
+        // the next tile's first barrier orders these LDS reads before its staging writes
+    }
+    float *dst = partial + ((size_t)blockIdx.x * K + k) * Cin * Cout;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int blk = wave + 4 * a;
+        if (blk < nblk) {
+            const int ib = blk / ncb, cb = blk - ib * ncb;
+            const int co = cb * 32 + l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = acc[a][r];
+            }
+        }
+    }
+}
+
+static bool sp_geom_ok(const int *g) {
+    for (int i = 0; i < 6; ++i)
+        if (g[i] < 1) return false;
+    for (int i = 6; i < 9; ++i)
+        if (g[i] < 0) return false;
+    for (int i = 9; i < 15; ++i)
+        if (g[i] < 1) return false;
+    return true;
+}
+
+}  // namespace mgar
+
+using namespace mgar;
+
+#define SP_API extern "C" __attribute__((visibility("default")))
+
+// Hash table over the voxel coordinates coords (N, 4) int32 [b, z, y, x] of a (Z, Y, X) grid.  table_keys (capacity) int64
+// must be pre-filled with -1 and table_vals (capacity) int32 with INT_MAX by the caller; capacity a power of two >= 2 N.
+SP_API int mgar_voxel_hash_build(int N, const int *coords, int Z, int Y, int X, long long *table_keys, int *table_vals,
+                                 int capacity, void *stream) {
+    MGAR_REQUIRE(N >= 0 && Z > 0 && Y > 0 && X > 0 && capacity > 0 && (capacity & (capacity - 1)) == 0 && capacity >= 2 * N,
+                 "voxel_hash_build: capacity must be a power of two >= 2 N");
+    if (N == 0) return MGAR_OK;
+    MGAR_REQUIRE(coords && table_keys && table_vals, "voxel_hash_build: null pointer");
+    hipLaunchKernelGGL(sph_build_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, N, coords, Z, Y, X, table_keys,
+                       table_vals, capacity - 1);
+    return check_launch("voxel_hash_build: launch failed");
+}
+
+// rows[i] = row id stored for coords[i] (M, 4), or -1 (the sparse replacement of indexing the dense (B, Z, Y, X) table of
+// pcdet/utils/common_utils.py:244-252)
+SP_API int mgar_voxel_hash_lookup(int M, const int *coords, int Z, int Y, int X, const long long *table_keys, const int *table_vals,
+                                  int capacity, int *rows, void *stream) {
+    MGAR_REQUIRE(M >= 0 && Z > 0 && Y > 0 && X > 0 && capacity > 0 && (capacity & (capacity - 1)) == 0, "voxel_hash_lookup: bad sizes");
+    if (M == 0) return MGAR_OK;
+    MGAR_REQUIRE(coords && table_keys && table_vals && rows, "voxel_hash_lookup: null pointer");
+    hipLaunchKernelGGL(sph_lookup_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, M, coords, Z, Y, X, table_keys,
+                       table_vals, capacity - 1, rows);
+    return check_launch("voxel_hash_lookup: launch failed");
+}
+
+// Rulebook of one sparse convolution.  geom: 15 HOST ints {kz,ky,kx, sz,sy,sx, pz,py,px, Zi,Yi,Xi, Zo,Yo,Xo}.
+//   inverse = 0: site_coords = OUTPUT sites (No, 4), table = hash of the INPUT sites -> nbr (No, K): input row under offset k
+//   inverse = 1: site_coords = INPUT sites (Ni, 4), table = hash of the OUTPUT sites -> nbr (Ni, K): output row reached through k
+// K = kz * ky * kx, offsets ordered z-major (k = (kz * KY + ky) * KX + kx, the order of spconv's (O, kd, kh, kw, I) weight).
+SP_API int mgar_spconv_rulebook(int n_sites, const int *site_coords, const int *geom, const long long *table_keys,
+                                const int *table_vals, int capacity, int inverse, int *nbr, void *stream) {
+    MGAR_REQUIRE(n_sites >= 0 && geom && sp_geom_ok(geom) && capacity > 0 && (capacity & (capacity - 1)) == 0, "spconv_rulebook: bad geometry");
+    if (n_sites == 0) return MGAR_OK;
+    MGAR_REQUIRE(site_coords && table_keys && table_vals && nbr, "spconv_rulebook: null pointer");
+    SpGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10], geom[11], geom[12],
+             geom[13], geom[14]};
+    const int K = g.kz * g.ky * g.kx;
+    const long long total = (long long)n_sites * K;
+    MGAR_REQUIRE(total / 256 < 2147483647LL, "spconv_rulebook: too many (site, offset) pairs");
+    if (inverse)
+        hipLaunchKernelGGL(sp_neighbors_inverse_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, K, site_coords,
+                           g, table_keys, table_vals, capacity - 1, nbr);
+    else
+        hipLaunchKernelGGL(sp_neighbors_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, K, site_coords, g,
+                           table_keys, table_vals, capacity - 1, nbr);
+    return check_launch("spconv_rulebook: launch failed");
+}
+
+// out (No, Cout) = sum_k in[nbr[:, k]] . w[k]   with w (K, Cin, Cout) row-major; rows with nbr == -1 contribute nothing.
+// flip_k != 0 reads w[K - 1 - k] (data gradient of a submanifold convolution: its inverse rulebook is the forward one
+// with the offsets mirrored).  out is fully written.  Cin, Cout <= 128.
+SP_API int mgar_spconv_gather_gemm(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *w, int flip_k,
+                                   float *out, void *stream) {
+    MGAR_REQUIRE(No >= 0 && K >= 1 && K <= 343 && Cin >= 1 && Cout >= 1, "spconv_gather_gemm: bad sizes");
+    if (Cin > SC_MAXC || Cout > SC_MAXC) {
+        set_error("spconv_gather_gemm: C_in, C_out <= 128");
+        return MGAR_EUNSUPPORTED;
+    }
+    if (No == 0) return MGAR_OK;
+    MGAR_REQUIRE(in && nbr && w && out, "spconv_gather_gemm: null pointer");
+    const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 1) & ~1;
+    const size_t lds = ((size_t)SC_ROWS * K + (size_t)SC_ROWS * (CinP + 1) + (size_t)CinP * CoutP) * sizeof(float);
+    MGAR_REQUIRE(lds <= 160 * 1024, "spconv_gather_gemm: tile does not fit LDS");
+    static size_t attr_lds = 0;
+    if (lds > 65536 && lds > attr_lds) {
+        (void)hipFuncSetAttribute((const void *)spconv_gather_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(spconv_gather_gemm_kernel, dim3(ceil_div(No, SC_ROWS)), dim3(256), lds, (hipStream_t)stream, No, K, Cin, Cout, in, nbr,
+                       w, flip_k, out);
+    return check_launch("spconv_gather_gemm: launch failed");
+}
+
+// weight gradient: partial (nchunk, K, Cin, Cout) with nchunk = mgar_spconv_dw_chunks(No); dW = partial.sum(0) (caller).
+SP_API int mgar_spconv_dw_chunks(int No) { return No < 0 ? MGAR_EINVAL : (No + SC_DW_CHUNK - 1) / SC_DW_CHUNK; }
+SP_API int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *dout, float *partial,
+                          void *stream) {
+    MGAR_REQUIRE(No >= 0 && K >= 1 && K <= 65535 && Cin >= 1 && Cout >= 1, "spconv_dw: bad sizes");
+    if (Cin > SC_MAXC || Cout > SC_MAXC) {
+        set_error("spconv_dw: C_in, C_out <= 128");
+        return MGAR_EUNSUPPORTED;
+    }
+    if (No == 0) return MGAR_OK;
+    MGAR_REQUIRE(in && nbr && dout && partial, "spconv_dw: null pointer");
+    const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 31) & ~31;
+    const size_t lds = ((size_t)SC_ROWS * (CinP + 1) + (size_t)SC_ROWS * (CoutP + 1)) * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > 65536 && lds > attr_lds) {
+        (void)hipFuncSetAttribute((const void *)spconv_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL(spconv_dw_kernel, dim3((No + SC_DW_CHUNK - 1) / SC_DW_CHUNK, K), dim3(256), lds, (hipStream_t)stream, No, K, Cin,
+                       Cout, in, nbr, dout, partial);
+    return check_launch("spconv_dw: launch failed");
+}

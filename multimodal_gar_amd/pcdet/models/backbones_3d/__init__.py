@@ -1,10 +1,11 @@
 from .pointnet2_backbone import PointNet2MSG
+from .spconv_backbone import VoxelBackBone8x
 from .voxel_pyramid import SparseTensorLite, VoxelPyramidStandIn
 
 __all__ = {
     'PointNet2MSG': PointNet2MSG,
-    # spconv's VoxelBackBone8x is a third-party sparse-conv trunk (out of scope, SURVEY.md section 8f
-    # rank 1); the name resolves to a documented stand-in with the same outputs' structure.
-    'VoxelBackBone8x': VoxelPyramidStandIn,
+    # the reference's sparse trunk (spconv_backbone.py:69-170) on this repo's sparse-convolution kernels
+    'VoxelBackBone8x': VoxelBackBone8x,
+    # round-1 placeholder (average pooling + Linear), kept for A/B runs only
     'VoxelPyramidStandIn': VoxelPyramidStandIn,
 }

@@ -39,6 +39,14 @@ def voxel_query_wrapper(M, R1, R2, R3, nsample, radius, z_range, y_range, x_rang
     return 1
 
 
+def voxel_query_hash_wrapper(M, R1, R2, R3, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords, table, idx):
+    """voxel_query_wrapper with the voxel -> row lookups served by a sparse_ops.VoxelHash instead of the dense table."""
+    import torch
+    L.call("mgar_voxel_query_hash_stack", M, R1, R2, R3, nsample, float(radius), z_range, y_range, x_range, L.fptr(new_xyz), L.fptr(xyz),
+           L.iptr(new_coords), L.dev_ptr(table.keys, torch.int64), L.iptr(table.vals), table.capacity, L.iptr(idx), L.stream_of(xyz))
+    return 1
+
+
 def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     # pointnet2_stack re-exports the dense-batch FPS (pointnet2_stack/src/sampling_gpu.cu:25-140)
     L.call("mgar_fps_batch", b, n, m, L.fptr(points), L.fptr(temp), L.iptr(idx), L.stream_of(points))

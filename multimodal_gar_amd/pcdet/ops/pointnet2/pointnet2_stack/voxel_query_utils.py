@@ -20,14 +20,10 @@ class VoxelQuery(Function):
     @staticmethod
     def forward(ctx, max_range: List[int], radius: float, nsample: int, xyz: torch.Tensor,
                 new_xyz: torch.Tensor, new_coords: torch.Tensor, point_indices: torch.Tensor):
-        assert new_xyz.is_contiguous() and xyz.is_contiguous()
-        assert new_coords.is_contiguous() and point_indices.is_contiguous()
+        assert new_xyz.is_contiguous() and xyz.is_contiguous() and new_coords.is_contiguous()
         n_query = new_coords.shape[0]
-        _, gz, gy, gx = point_indices.shape
         idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
-        z_range, y_range, x_range = max_range
-        pointnet2.voxel_query_wrapper(n_query, gz, gy, gx, nsample, radius, z_range, y_range, x_range, new_xyz, xyz,
-                                      new_coords, point_indices, idx)
+        _query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices, idx)
         empty_ball_mask = idx[:, 0] == -1
         idx[empty_ball_mask] = 0
         ctx.mark_non_differentiable(idx, empty_ball_mask)
@@ -38,6 +34,21 @@ class VoxelQuery(Function):
         return None, None, None, None, None, None, None
 
 
+def _query(max_range, radius, nsample, xyz, new_xyz, new_coords, point_indices, idx):
+    """point_indices: the reference's dense (B, Z, Y, X) int32 table, or a sparse_ops.VoxelHash over the same voxels."""
+    z_range, y_range, x_range = max_range
+    n_query = new_coords.shape[0]
+    if torch.is_tensor(point_indices):
+        assert point_indices.is_contiguous()
+        _, gz, gy, gx = point_indices.shape
+        pointnet2.voxel_query_wrapper(n_query, gz, gy, gx, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
+                                      point_indices, idx)
+    else:
+        gz, gy, gx = point_indices.spatial_shape
+        pointnet2.voxel_query_hash_wrapper(n_query, gz, gy, gx, nsample, radius, z_range, y_range, x_range, new_xyz, xyz, new_coords,
+                                           point_indices, idx)
+
+
 voxel_query = VoxelQuery.apply
 
 
@@ -46,11 +57,8 @@ def voxel_query_raw(max_range, radius, nsample, xyz, new_xyz, new_coords, point_
     (voxel_query_gpu.cu:10-89), without the mask / zero-fill post-processing of VoxelQuery -- what the fused pooling
     kernel consumes."""
     n_query = new_coords.shape[0]
-    _, gz, gy, gx = point_indices.shape
     idx = torch.zeros((n_query, nsample), dtype=torch.int32, device=xyz.device)
-    z_range, y_range, x_range = max_range
-    pointnet2.voxel_query_wrapper(n_query, gz, gy, gx, nsample, radius, z_range, y_range, x_range, new_xyz.contiguous(),
-                                  xyz.contiguous(), new_coords.contiguous(), point_indices.contiguous(), idx)
+    _query(max_range, radius, nsample, xyz.contiguous(), new_xyz.contiguous(), new_coords.contiguous(), point_indices, idx)
     return idx
 
 

@@ -42,8 +42,22 @@ def scatter_point_inds(indices, point_inds, shape):
     return ret
 
 
-def generate_voxel2pinds(sparse_tensor):
-    """Dense (B, Z, Y, X) int32 table: row id of the voxel in each occupied cell, -1 elsewhere."""
+DENSE_VOXEL2PINDS_MAX_CELLS = 1 << 26     # 256 MB of int32: beyond this the lookup structure is a hash table
+
+
+def generate_voxel2pinds(sparse_tensor, dense=None):
+    """Voxel -> row lookup of a sparse tensor.  dense=True: the reference's (B, Z, Y, X) int32 table (row id in each
+    occupied cell, -1 elsewhere; common_utils.py:244-252).  dense=False: a sparse_ops.VoxelHash over the same voxels, which
+    the voxel query consumes directly (csrc/voxel_query.hip, identical results) -- O(active voxels) instead of 80 MB per
+    sample at the shipped grid.  dense=None: the table while it is small, the hash beyond DENSE_VOXEL2PINDS_MAX_CELLS."""
+    if dense is None:
+        cells = sparse_tensor.batch_size
+        for s in sparse_tensor.spatial_shape:
+            cells *= int(s)
+        dense = cells <= DENSE_VOXEL2PINDS_MAX_CELLS or not sparse_tensor.indices.is_cuda
+    if not dense:
+        from ...sparse_ops import VoxelHash
+        return VoxelHash(sparse_tensor.indices.int().contiguous(), sparse_tensor.spatial_shape)
     indices = sparse_tensor.indices.long()
     rows = torch.arange(indices.shape[0], device=indices.device, dtype=torch.int32)
     return scatter_point_inds(indices, rows, [sparse_tensor.batch_size] + list(sparse_tensor.spatial_shape))

@@ -1,0 +1,160 @@
+"""Sparse 3-D convolution on the kernels of csrc/sparse_conv.hip: voxel hash table, rulebook (neighbour tables built on
+the device) and the gather-GEMM convolution with its two gradients.  This is what stands behind the ``spconv`` namespace
+of pcdet/utils/spconv_utils.py (the reference imports the third-party spconv 2.2.3 there: spconv_utils.py:3-6).
+
+Semantics (published definition of the two layers; spconv itself is neither vendored nor installed):
+  out[o] = sum_k W_k . in[i]   over the kernel offsets k whose input site i = o * stride - pad + k is active;
+  SubMConv3d   : output sites = input sites (stride 1, "same" padding);
+  SparseConv3d : output sites = every o in the output grid with at least one active input under its kernel, listed in
+                 ascending (b, z, y, x) order; output grid = floor((in + 2 pad - k) / stride) + 1.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+
+INT_MAX = 2 ** 31 - 1
+
+
+def _triple(v):
+    return tuple(int(x) for x in v) if isinstance(v, (list, tuple)) else (int(v),) * 3
+
+
+class VoxelHash:
+    """(b, z, y, x) -> row id over the active voxels of a (Z, Y, X) grid: the sparse replacement of the dense (B, Z, Y, X)
+    table of generate_voxel2pinds (reference pcdet/utils/common_utils.py:244-252; 80 MB per sample at the shipped grid)."""
+
+    def __init__(self, indices, spatial_shape):
+        assert indices.is_cuda and indices.dtype == torch.int32 and indices.dim() == 2 and indices.shape[1] == 4
+        self.indices = indices.contiguous()
+        self.spatial_shape = [int(s) for s in spatial_shape]
+        n = indices.shape[0]
+        cap = 16
+        while cap < 2 * n:
+            cap *= 2
+        self.capacity = cap
+        self.keys = torch.full((cap,), -1, dtype=torch.int64, device=indices.device)
+        self.vals = torch.full((cap,), INT_MAX, dtype=torch.int32, device=indices.device)
+        z, y, x = self.spatial_shape
+        L.call("mgar_voxel_hash_build", n, L.iptr(self.indices), z, y, x, L.dev_ptr(self.keys, torch.int64), L.iptr(self.vals), cap,
+               L.stream_of(indices))
+
+    def lookup(self, coords):
+        """coords (M, 4) int32 [b, z, y, x] -> rows (M) int32, -1 where no active voxel."""
+        coords = coords.contiguous().int()
+        rows = torch.empty((coords.shape[0],), dtype=torch.int32, device=coords.device)
+        z, y, x = self.spatial_shape
+        L.call("mgar_voxel_hash_lookup", coords.shape[0], L.iptr(coords), z, y, x, L.dev_ptr(self.keys, torch.int64), L.iptr(self.vals),
+               self.capacity, L.iptr(rows), L.stream_of(coords))
+        return rows
+
+
+class Rulebook:
+    """Neighbour tables of one (input sites, kernel, stride, padding) combination; shared by every convolution with the
+    same ``indice_key`` (as spconv shares its indice pairs)."""
+
+    def __init__(self, indices, spatial_shape, batch_size, kernel, stride, padding, subm):
+        import ctypes
+        self.kernel, self.stride, self.padding, self.subm = _triple(kernel), _triple(stride), _triple(padding), bool(subm)
+        kz, ky, kx = self.kernel
+        self.K = kz * ky * kx
+        self.in_indices = indices.contiguous()
+        self.in_shape = [int(s) for s in spatial_shape]
+        dev = indices.device
+        in_hash = VoxelHash(self.in_indices, self.in_shape)
+        if self.subm:
+            assert self.stride == (1, 1, 1) and all(2 * p == k - 1 for p, k in zip(self.padding, self.kernel)), \
+                "submanifold convolution: stride 1, odd kernel, padding k // 2"
+            self.out_indices, self.out_shape = self.in_indices, list(self.in_shape)
+        else:
+            self.out_shape = [(s + 2 * p - k) // st + 1 for s, p, k, st in zip(self.in_shape, self.padding, self.kernel, self.stride)]
+            self.out_indices = self._output_sites()
+        geom = (ctypes.c_int * 15)(*self.kernel, *self.stride, *self.padding, *self.in_shape, *self.out_shape)
+        n_out = self.out_indices.shape[0]
+        self.nbr = torch.empty((n_out, self.K), dtype=torch.int32, device=dev)
+        L.call("mgar_spconv_rulebook", n_out, L.iptr(self.out_indices), geom, L.dev_ptr(in_hash.keys, torch.int64), L.iptr(in_hash.vals),
+               in_hash.capacity, 0, L.iptr(self.nbr), L.stream_of(indices))
+        self.inv = None             # submanifold: the inverse table is the forward one with mirrored offsets
+        if not self.subm:
+            out_hash = VoxelHash(self.out_indices, self.out_shape)
+            self.inv = torch.empty((self.in_indices.shape[0], self.K), dtype=torch.int32, device=dev)
+            L.call("mgar_spconv_rulebook", self.in_indices.shape[0], L.iptr(self.in_indices), geom, L.dev_ptr(out_hash.keys, torch.int64),
+                   L.iptr(out_hash.vals), out_hash.capacity, 1, L.iptr(self.inv), L.stream_of(indices))
+
+    def _output_sites(self):
+        """Active output sites of a strided convolution: every o = (i + pad - k) / stride that is integral and inside the
+        output grid, over all active inputs i and offsets k; unique, ascending in (b, z, y, x)."""
+        idx = self.in_indices.long()
+        zo, yo, xo = self.out_shape
+        keys = []
+        for kz in range(self.kernel[0]):
+            nz = idx[:, 1] + self.padding[0] - kz
+            okz = (nz >= 0) & (nz % self.stride[0] == 0) & (nz // self.stride[0] < zo)
+            for ky in range(self.kernel[1]):
+                ny = idx[:, 2] + self.padding[1] - ky
+                oky = okz & (ny >= 0) & (ny % self.stride[1] == 0) & (ny // self.stride[1] < yo)
+                for kx in range(self.kernel[2]):
+                    nx = idx[:, 3] + self.padding[2] - kx
+                    ok = oky & (nx >= 0) & (nx % self.stride[2] == 0) & (nx // self.stride[2] < xo)
+                    key = ((idx[:, 0] * zo + nz // self.stride[0]) * yo + ny // self.stride[1]) * xo + nx // self.stride[2]
+                    keys.append(key[ok])
+        uniq = torch.unique(torch.cat(keys))
+        b = uniq // (zo * yo * xo)
+        r = uniq % (zo * yo * xo)
+        return torch.stack([b, r // (yo * xo), (r % (yo * xo)) // xo, r % xo], 1).int().contiguous()
+
+
+def _gather_gemm(n_out, k, cin, cout, feats, nbr, w, flip):
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    L.call("mgar_spconv_gather_gemm", n_out, k, cin, cout, L.fptr(feats), L.iptr(nbr), L.fptr(w), int(flip), L.fptr(out),
+           L.stream_of(feats))
+    return out
+
+
+class _SparseConv(Function):
+    """out (No, Cout) = sum_k feats[nbr[:, k]] @ w[k]  with w (K, Cin, Cout)."""
+
+    @staticmethod
+    def forward(ctx, feats, w, rb):
+        feats, w = feats.contiguous().float(), w.contiguous().float()
+        k, cin, cout = w.shape
+        out = _gather_gemm(rb.nbr.shape[0], k, cin, cout, feats, rb.nbr, w, 0)
+        ctx.save_for_backward(feats, w)
+        ctx.rb = rb
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        feats, w = ctx.saved_tensors
+        rb = ctx.rb
+        k, cin, cout = w.shape
+        dout = dout.contiguous().float()
+        dfeats = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = w.transpose(1, 2).contiguous()                                   # (K, Cout, Cin)
+            table = rb.nbr if rb.subm else rb.inv
+            dfeats = _gather_gemm(feats.shape[0], k, cout, cin, dout, table, wt, 1 if rb.subm else 0)
+        if ctx.needs_input_grad[1]:
+            n_out = rb.nbr.shape[0]
+            nchunk = L.raw("mgar_spconv_dw_chunks", n_out)
+            part = torch.empty((max(nchunk, 1), k, cin, cout), dtype=torch.float32, device=feats.device)
+            L.call("mgar_spconv_dw", n_out, k, cin, cout, L.fptr(feats), L.iptr(rb.nbr), L.fptr(dout), L.fptr(part), L.stream_of(feats))
+            dw = part.sum(0) if nchunk > 0 else torch.zeros_like(w)
+        return dfeats, dw, None
+
+
+def sparse_conv3d(features, indices, spatial_shape, batch_size, weight, kernel, stride, padding, subm, cache, key):
+    """One sparse convolution.  weight: the module's parameter in spconv 2.x layout (Cout, kz, ky, kx, Cin).
+    -> (out_features (No, Cout), out_indices (No, 4) int32, out_spatial_shape).  ``cache`` / ``key``: the rulebook of an
+    indice_key is built once per sparse tensor lineage and shared (spconv's indice_dict)."""
+    rb = cache.get(key) if key is not None else None
+    if rb is None or rb.in_indices.data_ptr() != indices.data_ptr() or rb.in_indices.shape != indices.shape:
+        rb = Rulebook(indices, spatial_shape, batch_size, kernel, stride, padding, subm)
+        if key is not None:
+            cache[key] = rb
+    cout, cin = weight.shape[0], weight.shape[-1]
+    w = weight.permute(1, 2, 3, 4, 0).reshape(rb.K, cin, cout)
+    out = _SparseConv.apply(features, w, rb)
+    return out, rb.out_indices, rb.out_shape

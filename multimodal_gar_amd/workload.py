@@ -229,35 +229,12 @@ class ClipModel(nn.Module):
             return self.net.GAR_model(pad(rgb_s.float()), pad(lidar.float()), bb2, batch["bboxes3d"], None, batch["person_id"])
 
 
-def voxelize_batch(points, dataset, max_points=5):
-    """(F, P, 4) -> the dict MeanVFE / the trunk stand-in consume (voxels, counts, coords [b,z,y,x]).
-    Device-side restatement of the reference's host voxeliser call (data_processor.py:15-60); the
-    voxeliser itself is a 'next' item, this is only input plumbing."""
-    f, p, c = points.shape
-    dev = points.device
-    lo = torch.tensor(dataset.point_cloud_range[:3], device=dev)
-    vs = torch.tensor(dataset.voxel_size, device=dev, dtype=points.dtype)
-    gx, gy, gz = [int(v) for v in dataset.grid_size]
-    ijk = torch.floor((points[..., :3] - lo) / vs).long()
-    ok = ((ijk >= 0) & (ijk < torch.tensor([gx, gy, gz], device=dev))).all(-1)
-    bidx = torch.arange(f, device=dev).view(f, 1).expand(f, p)
-    key = ((bidx * gz + ijk[..., 2]) * gy + ijk[..., 1]) * gx + ijk[..., 0]
-    key = torch.where(ok, key, torch.full_like(key, -1)).view(-1)
-    flat = points.view(-1, c)[key >= 0]
-    key = key[key >= 0]
-    uniq, inv, counts = torch.unique(key, return_inverse=True, return_counts=True)
-    v = uniq.numel()
-    # rank of each point inside its voxel (stable), keep the first max_points
-    order = torch.argsort(inv, stable=True)
-    start = torch.cumsum(counts, 0) - counts
-    rank = torch.empty_like(order)
-    rank[order] = torch.arange(order.numel(), device=dev) - start[inv[order]]
-    keep = rank < max_points
-    voxels = torch.zeros((v, max_points, c), device=dev, dtype=points.dtype)
-    voxels[inv[keep], rank[keep]] = flat[keep]
-    zyx = torch.stack([uniq // (gx * gy * gz), (uniq // (gx * gy)) % gz, (uniq // gx) % gy, uniq % gx], 1).int()
-    return {"batch_size": f, "voxels": voxels, "voxel_num_points": counts.clamp(max=max_points).to(points.dtype),
-            "voxel_coords": zyx}
+def voxelize_batch(points, dataset, max_points=5, max_voxels=40000):
+    """(F, P, 4) -> the dict MeanVFE / the sparse trunk consume (voxels, counts, coords [b, z, y, x]): the reference's host
+    voxeliser call (pcdet/datasets/processor/data_processor.py:15-60, 132-152) for all clouds of the batch at once, on the
+    tensors' device, with the same semantics (first-appearance voxel order, first max_points points, max_voxels cap)."""
+    from .pcdet.datasets.processor.data_processor import points_to_voxels_batch
+    return points_to_voxels_batch(points, dataset.point_cloud_range, dataset.voxel_size, max_points, max_voxels)
 
 
 def synthetic_loss(outputs):

@@ -201,11 +201,39 @@ class _GatAggregateCpu:
         return out.view(n, heads * c), alpha
 
 
+def sparse_conv3d_dense(features, indices, spatial_shape, batch_size, weight, kernel, stride, padding, subm, cache, key):
+    """Oracle of the sparse convolutions (multimodal_gar_amd/sparse_ops.py): the DENSE conv3d of the densified tensor,
+    read back at the active output sites (submanifold: the input sites; strided: every output cell whose receptive field
+    holds an active input, in ascending (b, z, y, x) order).  Plain torch on CPU, differentiable through autograd."""
+    import torch.nn.functional as F
+    z, y, x = [int(s) for s in spatial_shape]
+    idx = indices.long()
+    c = features.shape[1]
+    dense = features.new_zeros((batch_size, z, y, x, c))
+    dense = dense.index_put((idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]), features).permute(0, 4, 1, 2, 3)
+    w = weight.permute(0, 4, 1, 2, 3)                                  # (Cout, kz, ky, kx, Cin) -> (Cout, Cin, kz, ky, kx)
+    st = tuple(stride) if isinstance(stride, (list, tuple)) else (stride,) * 3
+    pd = tuple(padding) if isinstance(padding, (list, tuple)) else (padding,) * 3
+    kk = tuple(kernel) if isinstance(kernel, (list, tuple)) else (kernel,) * 3
+    if subm:
+        st, pd = (1, 1, 1), tuple(k // 2 for k in kk)
+    out = F.conv3d(dense, w, stride=st, padding=pd)
+    if subm:
+        oidx = idx
+    else:
+        occ = features.new_zeros((batch_size, 1, z, y, x))
+        occ[idx[:, 0], 0, idx[:, 1], idx[:, 2], idx[:, 3]] = 1.0
+        hit = F.conv3d(occ, occ.new_ones((1, 1) + kk), stride=st, padding=pd)[:, 0] > 0.5
+        oidx = hit.nonzero()
+    feats = out[oidx[:, 0], :, oidx[:, 1], oidx[:, 2], oidx[:, 3]]
+    return feats, oidx.int().contiguous(), list(out.shape[2:])
+
+
 @contextlib.contextmanager
 def use_cpu_oracle():
     from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as bmod
     from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as smod
-    from multimodal_gar_amd import vision_ops, dafm_ops, graph_ops
+    from multimodal_gar_amd import vision_ops, dafm_ops, graph_ops, sparse_ops
     from multimodal_gar_amd.model import gat_model
     O.build()
     saved = []
@@ -222,6 +250,7 @@ def use_cpu_oracle():
     patch(dafm_ops, "dafm_attention", dafm_attention_cpu)
     patch(gat_model, "dafm_attention", dafm_attention_cpu)
     patch(graph_ops, "_GatAggregate", _GatAggregateCpu)
+    patch(sparse_ops, "sparse_conv3d", sparse_conv3d_dense)
     try:
         yield
     finally:

@@ -304,3 +304,36 @@ def gatv2(x, edge_index, w_l, b_l, w_r, b_r, att, bias, heads, out_ch, slope=0.2
         out[i] = (al[:, :, None] * xl[src[m]]).sum(0)
     out = out.reshape(n, heads * out_ch) if concat else out.mean(1)
     return out + np.asarray(bias, np.float64)
+
+
+def voxelize_points_loop(points, vsize_xyz, coors_range_xyz, max_num_points_per_voxel, max_num_voxels):
+    """The literal sequential algorithm of the voxel generator the reference wraps
+    (pcdet/datasets/processor/data_processor.py:15-60 -> spconv Point2VoxelCPU3d, third-party, restated from its published
+    behaviour; see multimodal_gar_amd/pcdet/datasets/processor/data_processor.py).  Pure Python loop: small cases only.
+    points (N, C) float32 -> (voxels (V, max_points, C), coordinates (V, 3) [z, y, x] int32, num_points (V) int32)."""
+    import numpy as np
+    points = np.asarray(points, np.float32)
+    lo = np.asarray(coors_range_xyz[:3], np.float32)
+    vs = np.asarray(vsize_xyz, np.float32)
+    grid = np.round((np.asarray(coors_range_xyz[3:6], np.float64) - np.asarray(coors_range_xyz[:3], np.float64))
+                    / np.asarray(vsize_xyz, np.float64)).astype(np.int64)
+    index, voxels, coords, counts = {}, [], [], []
+    for pt in points:
+        c = np.floor((pt[:3] - lo) / vs).astype(np.int64)          # float32 arithmetic, as the device path
+        if (c < 0).any() or (c >= grid).any():
+            continue
+        key = (int(c[2]), int(c[1]), int(c[0]))
+        v = index.get(key)
+        if v is None:
+            if len(voxels) >= max_num_voxels:
+                continue
+            v = index[key] = len(voxels)
+            voxels.append(np.zeros((max_num_points_per_voxel, points.shape[1]), np.float32))
+            coords.append(key)
+            counts.append(0)
+        if counts[v] < max_num_points_per_voxel:
+            voxels[v][counts[v]] = pt
+            counts[v] += 1
+    if not voxels:
+        return (np.zeros((0, max_num_points_per_voxel, points.shape[1]), np.float32), np.zeros((0, 3), np.int32), np.zeros((0,), np.int32))
+    return np.stack(voxels), np.asarray(coords, np.int32), np.asarray(counts, np.int32)
