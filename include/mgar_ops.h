@@ -433,6 +433,21 @@ int mgar_spconv_dw_chunks(int No);
 int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *dout,
                    float *partial, void *stream);
 
+/* ===================== per-actor point crop ========================
+ * points_in_boxes_gpu   pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-116; kernel roiaware_pool3d_kernel.cu:313-334
+ * boxes (B, N, 7) [x, y, z, dx, dy, dz, heading], pts (B, P, 3) -> box_idx_of_points (B, P): index of the FIRST box
+ * containing the point, -1 = background.  Every entry is written. */
+int mgar_points_in_boxes(int batch_size, int boxes_num, int pts_num, const float *boxes, const float *pts,
+                         int *box_idx_of_points, void *stream);
+/* roipool3d_gpu / roipool3dLauncher   pcdet/ops/roipoint_pool3d/src/roipoint_pool3d.cpp:23-51, roipoint_pool3d_kernel.cu:138-166
+ * xyz (B, N, 3), boxes3d (B, M, 7), pts_feature (B, N, C) -> pooled_features (B, M, S, 3 + C): the first S points (in
+ * index order) inside each box, cyclically repeated when fewer; pooled_empty_flag (B, M) = 1 for a box without points,
+ * whose rows are left untouched.  Both outputs are ZERO-FILLED by the caller (roipoint_pool3d_utils.py:50-51).  Unlike
+ * the reference this neither allocates nor uses an O(B*N*M) scratch. */
+int mgar_roipoint_pool3d_fwd(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
+                             const float *xyz, const float *boxes3d, const float *pts_feature, float *pooled_features,
+                             int *pooled_empty_flag, void *stream);
+
 /* ============================ bf16 feature payloads (BASELINE configs c2, c5) ============================
  * The reference's kernels are fp32 + int32 only.  For the bf16 configurations SURVEY.md section 8 keeps coordinates,
  * distances, indices and BatchNorm statistics in fp32 / int32 and stores only FEATURE PAYLOADS (and runs the GEMMs) in

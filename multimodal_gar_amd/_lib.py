@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -79,6 +79,8 @@ _PROTOS = {
     "mgar_dafm_attn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P],
     "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_points_in_boxes": [_I, _I, _I, _P, _P, _P, _P],
+    "mgar_roipoint_pool3d_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_hash_build": [_I, _P, _I, _I, _I, _P, _P, _I, _P],
     "mgar_voxel_hash_lookup": [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "mgar_spconv_rulebook": [_I, _P, _P, _P, _P, _I, _I, _P, _P],

@@ -82,7 +82,9 @@ def model_cfg(n_actors, n_points, gat=True, route="pointnet2"):
 class SyntheticDataset:
     """The attributes pcdet's detector template reads from a dataset (detector3d_template.py:36-44)."""
 
-    def __init__(self, voxel_size=(0.25, 0.25, 0.5)):
+    def __init__(self, voxel_size=(0.25, 0.25, 0.1)):
+        # 160 x 160 x 40 cells over the 40 m x 40 m x 4 m range: 40 cells in z like the shipped grid (mil3.yaml:40,56), which is
+        # what VoxelBackBone8x's four z-halvings assume (41 -> 21 -> 11 -> 5 -> 2, spconv_backbone.py:85-117)
         self.class_names = ["Pedestrian"]
         self.point_feature_encoder = EasyDict(num_point_features=4)
         self.point_cloud_range = np.array(PC_RANGE, np.float32)

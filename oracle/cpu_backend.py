@@ -201,6 +201,17 @@ class _GatAggregateCpu:
         return out.view(n, heads * c), alpha
 
 
+def roipoint_pool3d_forward_cpu(xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag):
+    O.lib().orc_roipoint_pool3d(xyz.shape[0], xyz.shape[1], boxes3d.shape[1], pts_feature.shape[2], pooled_features.shape[2],
+                                _p(xyz), _p(boxes3d), _p(pts_feature), _p(pooled_features), _p(pooled_empty_flag))
+    return 1
+
+
+def points_in_boxes_cpu(boxes, pts, box_idx_of_points):
+    O.lib().orc_points_in_boxes(boxes.shape[0], boxes.shape[1], pts.shape[1], _p(boxes), _p(pts), _p(box_idx_of_points))
+    return 1
+
+
 def sparse_conv3d_dense(features, indices, spatial_shape, batch_size, weight, kernel, stride, padding, subm, cache, key):
     """Oracle of the sparse convolutions (multimodal_gar_amd/sparse_ops.py): the DENSE conv3d of the densified tensor,
     read back at the active output sites (submanifold: the input sites; strided: every output cell whose receptive field
@@ -251,6 +262,10 @@ def use_cpu_oracle():
     patch(gat_model, "dafm_attention", dafm_attention_cpu)
     patch(graph_ops, "_GatAggregate", _GatAggregateCpu)
     patch(sparse_ops, "sparse_conv3d", sparse_conv3d_dense)
+    from multimodal_gar_amd.pcdet.ops.roipoint_pool3d import roipoint_pool3d_cuda as rpmod
+    from multimodal_gar_amd.pcdet.ops.roiaware_pool3d import roiaware_pool3d_cuda as ramod
+    patch(rpmod, "forward", roipoint_pool3d_forward_cpu)
+    patch(ramod, "points_in_boxes_gpu", points_in_boxes_cpu)
     try:
         yield
     finally:

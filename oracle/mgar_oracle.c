@@ -497,3 +497,71 @@ ORC_API void orc_roi_align_fwd(const float *input, int N, int C, int H, int W, c
         }
     }
 }
+
+
+/* ======================= per-actor point crop ==========================
+ * pcdet/ops/roiaware_pool3d/src/roiaware_pool3d_kernel.cu:18-37 (lidar_to_local_coords, check_pt_in_box3d), :313-334
+ * (points_in_boxes_kernel) and pcdet/ops/roipoint_pool3d/src/roipoint_pool3d_kernel.cu:15-135 (assign_pts_to_box3d,
+ * get_pooled_idx, roipool3d_forward).  Arithmetic as written there: the z test and the half-extent tests compare in
+ * double (dz / 2.0, dx / 2.0 + MARGIN with a float MARGIN), the rotation uses float cos / sin of -heading and
+ * un-contracted float products.  The box test is PINNED against the reference's own CPU build of the same test
+ * (roiaware_pool3d.cpp:118-168, MARGIN 1e-2 there; oracle/_ref, tests/test_point_crop_cpu.py). */
+static int orc_pt_in_box3d(const float *pt, const float *box3d, float margin, float *local_x, float *local_y) {
+    const float x = pt[0], y = pt[1], z = pt[2];
+    const float cx = box3d[0], cy = box3d[1], cz = box3d[2];
+    const float dx = box3d[3], dy = box3d[4], dz = box3d[5], rz = box3d[6];
+    if (fabsf(z - cz) > dz / 2.0) return 0;
+    const float shift_x = x - cx, shift_y = y - cy;
+    const float cosa = cosf(-rz), sina = sinf(-rz);
+    *local_x = shift_x * cosa + shift_y * (-sina);
+    *local_y = shift_x * sina + shift_y * cosa;
+    return (fabs(*local_x) < dx / 2.0 + margin) & (fabs(*local_y) < dy / 2.0 + margin);
+}
+
+/* (N boxes, P points) 0/1 matrix with an explicit margin: the shape of the reference's points_in_boxes_cpu */
+ORC_API void orc_points_in_boxes_mask(int boxes_num, int pts_num, const float *boxes, const float *pts, float margin, int *out) {
+    float lx, ly;
+    for (int i = 0; i < boxes_num; ++i)
+        for (int j = 0; j < pts_num; ++j) out[(size_t)i * pts_num + j] = orc_pt_in_box3d(pts + (size_t)j * 3, boxes + (size_t)i * 7, margin, &lx, &ly);
+}
+
+/* points_in_boxes_kernel: index of the FIRST box (ascending) holding each point, -1 = background (caller pre-fills) */
+ORC_API void orc_points_in_boxes(int batch_size, int boxes_num, int pts_num, const float *boxes, const float *pts,
+                                 int *box_idx_of_points) {
+    float lx, ly;
+    for (int b = 0; b < batch_size; ++b)
+        for (int p = 0; p < pts_num; ++p)
+            for (int k = 0; k < boxes_num; ++k)
+                if (orc_pt_in_box3d(pts + ((size_t)b * pts_num + p) * 3, boxes + ((size_t)b * boxes_num + k) * 7, 1e-5f, &lx, &ly)) {
+                    box_idx_of_points[(size_t)b * pts_num + p] = k;
+                    break;
+                }
+}
+
+/* roipool3dLauncher: the three kernels in sequence.  pooled_features (B, M, S, 3 + C) and pooled_empty_flag (B, M) are
+ * pre-zeroed by the caller (roipoint_pool3d_utils.py:50-51); rows of empty boxes are left untouched. */
+ORC_API void orc_roipoint_pool3d(int batch_size, int pts_num, int boxes_num, int feature_in_len, int sampled_pts_num,
+                                 const float *xyz, const float *boxes3d, const float *pts_feature, float *pooled_features,
+                                 int *pooled_empty_flag) {
+    float lx, ly;
+    int *pts_idx = (int *)malloc(sizeof(int) * (size_t)(sampled_pts_num > 0 ? sampled_pts_num : 1));
+    for (int b = 0; b < batch_size; ++b)
+        for (int m = 0; m < boxes_num; ++m) {
+            const float *box = boxes3d + ((size_t)b * boxes_num + m) * 7;
+            int cnt = 0;
+            for (int k = 0; k < pts_num && cnt < sampled_pts_num; ++k)
+                if (orc_pt_in_box3d(xyz + ((size_t)b * pts_num + k) * 3, box, 1e-5f, &lx, &ly)) pts_idx[cnt++] = k;
+            if (cnt == 0) {
+                pooled_empty_flag[(size_t)b * boxes_num + m] = 1;
+                continue;
+            }
+            for (int k = cnt; k < sampled_pts_num; ++k) pts_idx[k] = pts_idx[k % cnt];
+            for (int s = 0; s < sampled_pts_num; ++s) {
+                float *dst = pooled_features + (((size_t)b * boxes_num + m) * sampled_pts_num + s) * (3 + feature_in_len);
+                const int src = pts_idx[s];
+                for (int j = 0; j < 3; ++j) dst[j] = xyz[((size_t)b * pts_num + src) * 3 + j];
+                for (int j = 0; j < feature_in_len; ++j) dst[3 + j] = pts_feature[((size_t)b * pts_num + src) * feature_in_len + j];
+            }
+        }
+    free(pts_idx);
+}

@@ -337,3 +337,52 @@ def voxelize_points_loop(points, vsize_xyz, coors_range_xyz, max_num_points_per_
     if not voxels:
         return (np.zeros((0, max_num_points_per_voxel, points.shape[1]), np.float32), np.zeros((0, 3), np.int32), np.zeros((0,), np.int32))
     return np.stack(voxels), np.asarray(coords, np.int32), np.asarray(counts, np.int32)
+
+
+def points_in_boxes_mask(boxes, pts, margin):
+    """(N, P) int32 0/1: box test with an explicit margin (the shape of the reference's points_in_boxes_cpu)."""
+    boxes, pb = _f(boxes); pts, pp = _f(pts)
+    out = np.zeros((boxes.shape[0], pts.shape[0]), np.int32)
+    lib().orc_points_in_boxes_mask(boxes.shape[0], pts.shape[0], pb, pp, _cf(margin), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def points_in_boxes(boxes, pts):
+    """boxes (B, N, 7), pts (B, P, 3) -> (B, P) int32 index of the first box holding each point, -1 = none."""
+    boxes, pb = _f(boxes); pts, pp = _f(pts)
+    out = np.full(pts.shape[:2], -1, np.int32)
+    lib().orc_points_in_boxes(boxes.shape[0], boxes.shape[1], pts.shape[1], pb, pp, out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def roipoint_pool3d(xyz, boxes3d, pts_feature, sampled_pts_num):
+    """xyz (B, N, 3), boxes3d (B, M, 7) (already enlarged), pts_feature (B, N, C) -> (pooled (B, M, S, 3 + C), empty (B, M))."""
+    xyz, px = _f(xyz); boxes3d, pb = _f(boxes3d); pts_feature, pf = _f(pts_feature)
+    b, n, _ = xyz.shape
+    m, c = boxes3d.shape[1], pts_feature.shape[2]
+    pooled = np.zeros((b, m, sampled_pts_num, 3 + c), np.float32)
+    empty = np.zeros((b, m), np.int32)
+    lib().orc_roipoint_pool3d(b, n, m, c, sampled_pts_num, px, pb, pf, pooled.ctypes.data_as(ctypes.c_void_p),
+                              empty.ctypes.data_as(ctypes.c_void_p))
+    return pooled, empty
+
+
+def load_reference_roiaware():
+    """The reference's own roiaware_pool3d.cpp built by oracle/build_ref.sh (oracle/_ref/, build container only), or None.
+    Opened with lazy binding: the CUDA launchers the file declares are never defined nor called."""
+    import importlib.util
+    import os
+    import sys
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "roiaware_pool3d_ref.so")
+    if not os.path.exists(path):
+        return None
+    old = sys.getdlopenflags()
+    sys.setdlopenflags(os.RTLD_LAZY | os.RTLD_LOCAL)
+    try:
+        import torch  # noqa: F401  (libtorch must be loaded first)
+        spec = importlib.util.spec_from_file_location("roiaware_pool3d_ref", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    finally:
+        sys.setdlopenflags(old)

@@ -151,6 +151,7 @@ def test_voxel_query_through_hash_table_equals_dense_table(oracle):
     rng = np.random.default_rng(12)
     m = 600
     q = np.stack([rng.uniform(-5.5, 6.5, m), rng.uniform(-5.5, 5.5, m), rng.uniform(-2.5, 2.8, m)], 1).astype(np.float32)
+    q[:25] += 30.0                                        # far outside the grid: empty neighbourhoods
     cells = np.floor((q - lo) / vs).astype(np.int32)
     bidx = rng.integers(0, 2, m).astype(np.int32)
     order = np.argsort(bidx, kind="stable")
