@@ -249,8 +249,7 @@ def phase_timing(step, batch):
     pad = lambda x: torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2])], 1)  # noqa: E731
     bb2 = batch["bboxes"][:, None].expand(b, t, a + 1, 4).reshape(b * t, a + 1, 4)
     res = m.net.GAR_model(pad(rgb_s), pad(lidar), bb2, batch["bboxes3d"], None, batch["person_id"])
-    from multimodal_gar_amd.workload import synthetic_loss
-    loss = synthetic_loss(res); tick("fusion_fwd", t0)
+    loss = step._loss_of(res, batch); tick("fusion_fwd", t0)
     t0 = time.perf_counter(); loss.backward(); tick("backward", t0)
     t0 = time.perf_counter(); step.opt.step(); tick("adam", t0)
     return out

@@ -422,6 +422,10 @@ int mgar_voxel_hash_lookup(int M, const int *coords, int Z, int Y, int X, const 
  *                through offset k, or -1 (the data gradient gathers over this table). */
 int mgar_spconv_rulebook(int n_sites, const int *site_coords, const int *geom, const long long *table_keys,
                          const int *table_vals, int capacity, int inverse, int *nbr, void *stream);
+/* Candidate output sites of a strided convolution: keys (n_in, K) int64 = linear ((b*Zo + z)*Yo + y)*Xo + x key of the
+ * output site input i reaches through offset k, or -1.  The caller keeps the non-negative keys and makes them unique
+ * (ascending = the order of the output rows). */
+int mgar_spconv_output_keys(int n_in, const int *in_coords, const int *geom, long long *keys, void *stream);
 /* out (No, Cout) = sum_k in[nbr[:, k]] . w[k], w (K, Cin, Cout) row-major, fp32 on the exact-fp32 MFMA; rows with
  * nbr == -1 contribute nothing; out is fully written.  flip_k != 0 reads w[K-1-k] (data gradient of a submanifold
  * convolution over its own forward table).  Cin, Cout <= 128 (MGAR_EUNSUPPORTED otherwise). */

@@ -84,6 +84,7 @@ _PROTOS = {
     "mgar_voxel_hash_build": [_I, _P, _I, _I, _I, _P, _P, _I, _P],
     "mgar_voxel_hash_lookup": [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "mgar_spconv_rulebook": [_I, _P, _P, _P, _P, _I, _I, _P, _P],
+    "mgar_spconv_output_keys": [_I, _P, _P, _P, _P],
     "mgar_spconv_gather_gemm": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "mgar_spconv_dw_chunks": [_I],
     "mgar_spconv_dw": [_I, _I, _I, _I, _P, _P, _P, _P, _P],

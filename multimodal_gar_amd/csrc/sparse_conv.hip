@@ -96,6 +96,24 @@ __global__ __launch_bounds__(256) void sp_neighbors_inverse_kernel(long long tot
     inv[e] = r;
 }
 
+// candidate output sites of a strided convolution: keys[i * K + k] = linear (b, z, y, x) key in the OUTPUT grid of the site that
+// input i reaches through offset k, or -1 (not integral / outside the grid).  The caller keeps the non-negative keys and makes
+// them unique (one sort): ascending (b, z, y, x) order of the output sites.
+__global__ __launch_bounds__(256) void sp_output_keys_kernel(long long total, int K, const int *__restrict__ in_coords, SpGeom g,
+                                                             long long *__restrict__ keys) {
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long i = e / K;
+    const int k = (int)(e - i * K);
+    const int kx = k % g.kx, ky = (k / g.kx) % g.ky, kz = k / (g.kx * g.ky);
+    const int *c = in_coords + i * 4;
+    const int nz = c[1] + g.pz - kz, ny = c[2] + g.py - ky, nx = c[3] + g.px - kx;
+    long long key = SPH_EMPTY;
+    if (nz >= 0 && ny >= 0 && nx >= 0 && nz % g.sz == 0 && ny % g.sy == 0 && nx % g.sx == 0)
+        key = sph_key(c[0], nz / g.sz, ny / g.sy, nx / g.sx, g.Zo, g.Yo, g.Xo);
+    keys[e] = key;
+}
+
 // ---- gather-GEMM: out[o, :] = sum_k in[nbr[o, k], :] . W[k]  (W (K, Cin, Cout) row-major) ------------------------------
 constexpr int SC_ROWS = 64;       // output rows per workgroup
 constexpr int SC_MAXC = 128;      // C_in, C_out <= 128
@@ -308,6 +326,20 @@ SP_API int mgar_spconv_rulebook(int n_sites, const int *site_coords, const int *
         hipLaunchKernelGGL(sp_neighbors_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, K, site_coords, g,
                            table_keys, table_vals, capacity - 1, nbr);
     return check_launch("spconv_rulebook: launch failed");
+}
+
+// keys (n_in, K) int64: see sp_output_keys_kernel.  geom as in mgar_spconv_rulebook.
+SP_API int mgar_spconv_output_keys(int n_in, const int *in_coords, const int *geom, long long *keys, void *stream) {
+    MGAR_REQUIRE(n_in >= 0 && geom && sp_geom_ok(geom), "spconv_output_keys: bad geometry");
+    if (n_in == 0) return MGAR_OK;
+    MGAR_REQUIRE(in_coords && keys, "spconv_output_keys: null pointer");
+    SpGeom g{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10], geom[11], geom[12],
+             geom[13], geom[14]};
+    const int K = g.kz * g.ky * g.kx;
+    const long long total = (long long)n_in * K;
+    MGAR_REQUIRE(total / 256 < 2147483647LL, "spconv_output_keys: too many (site, offset) pairs");
+    hipLaunchKernelGGL(sp_output_keys_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, K, in_coords, g, keys);
+    return check_launch("spconv_output_keys: launch failed");
 }
 
 // out (No, Cout) = sum_k in[nbr[:, k]] . w[k]   with w (K, Cin, Cout) row-major; rows with nbr == -1 contribute nothing.

@@ -69,8 +69,9 @@ class Rulebook:
             self.out_indices, self.out_shape = self.in_indices, list(self.in_shape)
         else:
             self.out_shape = [(s + 2 * p - k) // st + 1 for s, p, k, st in zip(self.in_shape, self.padding, self.kernel, self.stride)]
-            self.out_indices = self._output_sites()
         geom = (ctypes.c_int * 15)(*self.kernel, *self.stride, *self.padding, *self.in_shape, *self.out_shape)
+        if not self.subm:
+            self.out_indices = self._output_sites(geom)
         n_out = self.out_indices.shape[0]
         self.nbr = torch.empty((n_out, self.K), dtype=torch.int32, device=dev)
         L.call("mgar_spconv_rulebook", n_out, L.iptr(self.out_indices), geom, L.dev_ptr(in_hash.keys, torch.int64), L.iptr(in_hash.vals),
@@ -82,24 +83,15 @@ class Rulebook:
             L.call("mgar_spconv_rulebook", self.in_indices.shape[0], L.iptr(self.in_indices), geom, L.dev_ptr(out_hash.keys, torch.int64),
                    L.iptr(out_hash.vals), out_hash.capacity, 1, L.iptr(self.inv), L.stream_of(indices))
 
-    def _output_sites(self):
+    def _output_sites(self, geom):
         """Active output sites of a strided convolution: every o = (i + pad - k) / stride that is integral and inside the
-        output grid, over all active inputs i and offsets k; unique, ascending in (b, z, y, x)."""
-        idx = self.in_indices.long()
+        output grid, over all active inputs i and offsets k (one kernel), made unique: ascending in (b, z, y, x)."""
+        n_in = self.in_indices.shape[0]
+        keys = torch.empty((n_in, self.K), dtype=torch.int64, device=self.in_indices.device)
+        L.call("mgar_spconv_output_keys", n_in, L.iptr(self.in_indices), geom, L.dev_ptr(keys, torch.int64), L.stream_of(keys))
+        keys = keys.view(-1)
+        uniq = torch.unique(keys[keys >= 0])
         zo, yo, xo = self.out_shape
-        keys = []
-        for kz in range(self.kernel[0]):
-            nz = idx[:, 1] + self.padding[0] - kz
-            okz = (nz >= 0) & (nz % self.stride[0] == 0) & (nz // self.stride[0] < zo)
-            for ky in range(self.kernel[1]):
-                ny = idx[:, 2] + self.padding[1] - ky
-                oky = okz & (ny >= 0) & (ny % self.stride[1] == 0) & (ny // self.stride[1] < yo)
-                for kx in range(self.kernel[2]):
-                    nx = idx[:, 3] + self.padding[2] - kx
-                    ok = oky & (nx >= 0) & (nx % self.stride[2] == 0) & (nx // self.stride[2] < xo)
-                    key = ((idx[:, 0] * zo + nz // self.stride[0]) * yo + ny // self.stride[1]) * xo + nx // self.stride[2]
-                    keys.append(key[ok])
-        uniq = torch.unique(torch.cat(keys))
         b = uniq // (zo * yo * xo)
         r = uniq % (zo * yo * xo)
         return torch.stack([b, r // (yo * xo), (r % (yo * xo)) // xo, r % xo], 1).int().contiguous()

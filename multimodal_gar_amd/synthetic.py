@@ -88,6 +88,30 @@ def scene_batch(seed, n_scenes, n_actors, n_points, num_boxes=None, height=720, 
     return {"points": pts, "bboxes3d": b3, "bboxes": b2, "person_id": pid}
 
 
+def scene_labels(seed, n_scenes, n_actors, num_boxes=None):
+    """Synthetic annotations of the shape the reference's dataloader yields (dataloader.py:245-253, 293): social_group_id
+    (n_scenes, num_boxes) int64 with -1 padding (2..A/3 groups per scene), action and social_group_activity
+    (n_scenes, num_boxes, 27) float32 multi-hot rows (one pose of each of the three pose groups, a few interactions)."""
+    rng = np.random.default_rng(seed)
+    num_boxes = num_boxes or (n_actors + 1)
+    gid = -np.ones((n_scenes, num_boxes), np.int64)
+    act = np.zeros((2, n_scenes, num_boxes, 27), np.float32)
+    for s in range(n_scenes):
+        n_groups = int(rng.integers(2, max(3, n_actors // 3 + 1)))
+        g = rng.integers(0, n_groups, n_actors)
+        g[:n_groups] = np.arange(n_groups)                       # every group id occurs
+        gid[s, :n_actors] = g
+    for a in act:
+        rows = a[:, :n_actors].reshape(-1, 27)
+        n = rows.shape[0]
+        rows[np.arange(n), rng.integers(0, 3, n)] = 1.0
+        rows[np.arange(n), 3 + rng.integers(0, 3, n)] = 1.0
+        rows[np.arange(n), 6 + rng.integers(0, 4, n)] = 1.0
+        rows[:, 11:25] = (rng.random((n, 14)) < 0.15).astype(np.float32)
+        a[:, :n_actors] = rows.reshape(n_scenes, n_actors, 27)
+    return {"social_group_id": gid, "action": act[0], "social_group_activity": act[1]}
+
+
 def images(seed, n_clips, n_frames, height, width):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((n_clips, n_frames, 3, height, width), dtype=np.float32)

@@ -1,0 +1,124 @@
+"""Grouping targets and label helpers of the training loop, on the tensors' device.
+
+Mirror of the public surface of the reference's train_utils.py: sid2AdjMat /
+batch_sid2AdjMat (:25-58), Adj2Deg / Adj2Lap (:60-80), get_num_person / get_num_social_group (:82-94), get_adjacency
+(:96-110), get_laplacian (:112-115), get_eig_loss2 (:117-144), get_label_from_action (:174-221).  Same names, arguments
+and return types, but without the reference's Python double loops over actors (get_adjacency fills a matrix element by
+element on the host and then copies it to the GPU, once per scene): every function is a handful of tensor ops on
+whatever device its inputs live on.  Results are identical: tests/test_train_utils_cpu.py holds them to fixtures produced
+by the reference's own functions (tests/golden/make_reference_train_utils_golden.py).
+"""
+import torch
+
+
+def LiDAR_feature_processing(data_dict):
+    """(B * P, D) shared feature -> zero-padded (B, 100, D) (reference :5-22)."""
+    shared = data_dict['shared_feature']
+    batch_size = data_dict['batch_size']
+    d = shared.shape[1]
+    shared = shared.reshape(batch_size, -1, d)
+    res = shared.new_zeros((batch_size, 100, d))
+    res[:, :shared.shape[1]] = shared
+    return res
+
+
+def sid2AdjMat(a):
+    """Group ids (n) with -1 padding -> (n, n): 1 for same group (and the diagonal), -1 on padded rows / columns.
+    The reference's loops stop at the first -1 (:29-40): entries beyond it stay 0 unless their row / column is padded."""
+    n = a.shape[0]
+    pad = a == -1
+    first_pad = torch.where(pad.any(), pad.float().argmax(), torch.tensor(n, device=a.device))
+    live = torch.arange(n, device=a.device) < first_pad
+    same = (a.view(-1, 1) == a.view(1, -1)) & live.view(-1, 1) & live.view(1, -1)
+    b = same.float()
+    b = torch.where(pad.view(-1, 1) | pad.view(1, -1), torch.full_like(b, -1.0), b)
+    return b
+
+
+def batch_sid2AdjMat(a):
+    return [sid2AdjMat(a[i]) for i in range(a.shape[0])]
+
+
+def Adj2Deg(A):
+    """(B, N, N) adjacency -> (B, N, N) diagonal degree matrices (column sums, :59-72)."""
+    return torch.diag_embed(torch.sum(A, dim=1))
+
+
+def Adj2Lap(A):
+    return Adj2Deg(A).to(A.device) - A
+
+
+def get_num_person(person_id):
+    """Number of distinct ids per sample minus one (the -1 padding is assumed present, :82-87).  Host ints, as the
+    reference returns (one sync for the whole batch instead of one per sample)."""
+    s, _ = torch.sort(person_id, dim=1)
+    distinct = 1 + (s[:, 1:] != s[:, :-1]).sum(1)
+    return [int(v) - 1 for v in distinct.tolist()]
+
+
+def get_num_social_group(social_group_id):
+    return get_num_person(social_group_id)
+
+
+def get_adjacency(social_group_id, person_num):
+    """-> list of (n_b, n_b) float matrices: 1 where two actors share a social group (and on the diagonal) (:96-110)."""
+    res = []
+    for b in range(social_group_id.shape[0]):
+        g = social_group_id[b, :person_num[b]]
+        res.append((g.view(-1, 1) == g.view(1, -1)).float())
+    return res
+
+
+def get_adjacency_batched(social_group_id, n):
+    """The same for a batch whose scenes all hold n actors: (B, n, n) in one op."""
+    g = social_group_id[:, :n]
+    return (g.unsqueeze(2) == g.unsqueeze(1)).float()
+
+
+def get_laplacian(A):
+    return torch.diag(torch.sum(A, dim=1)) - A
+
+
+def get_eig_loss2(A_theta_list, A_hat_list, alpha=1., beta=1.):
+    """Eigen loss of the reference (:117-144), statement for statement, including its conventions: eigen-decomposition of
+    L_hat^T L_hat with the general solver, eigenvalues tested for EXACT zero, and ``evecs[val]`` -- a ROW of the eigenvector
+    matrix -- taken as the vector.  (fp64; the loss is only part of the 'L_g' objective, train_func.py:240.)"""
+    dev = A_theta_list[0].device
+    eig_loss = torch.zeros((1,), requires_grad=True).to(dev)
+    for A_theta, A_hat in zip(A_theta_list, A_hat_list):
+        L_theta = get_laplacian(A_theta).double()
+        L_hat = get_laplacian(A_hat).double()
+        evals, evecs = torch.linalg.eig(torch.matmul(L_hat.T, L_hat))
+        zero = [evecs[v].double().unsqueeze(0) for v in range(evals.shape[0]) if torch.abs(evals[v]).item() == 0]
+        if len(zero) == 0:
+            return eig_loss
+        e_hat = torch.cat(zero, dim=0).to(dev)
+        first = torch.sum(torch.matmul(torch.matmul(torch.matmul(e_hat, L_theta.T), L_theta), e_hat.T))
+        L_bar = torch.matmul(L_theta, torch.eye(L_theta.shape[0], device=dev, dtype=L_theta.dtype) - torch.matmul(e_hat.T, e_hat))
+        second = alpha * torch.exp(-1 * beta * torch.trace(torch.matmul(L_bar.T, L_theta)))
+        eig_loss = eig_loss + first + second
+    return eig_loss
+
+
+def _labels(a):
+    """(..., n, 27) action one-hots -> the 7 label tensors of get_label_from_action for those rows."""
+    pose_1 = torch.cat((a[..., :3], a[..., 3:10].max(dim=-1, keepdim=True).values), dim=-1)
+    pose_2 = torch.cat((a[..., 3:6], a[..., 6:10].max(dim=-1, keepdim=True).values), dim=-1)
+    pose_3 = a[..., 6:10]
+    any_i = a[..., 11:25].max(dim=-1, keepdim=True).values
+    intrctn_1 = torch.cat((any_i, 1 - any_i), dim=-1)
+    intrctn_2 = torch.cat((a[..., 11:14], a[..., 14:25].max(dim=-1, keepdim=True).values), dim=-1)
+    intrctn_3 = torch.cat((a[..., 14:20], a[..., 20:25].max(dim=-1, keepdim=True).values), dim=-1)
+    intrctn_4 = a[..., 20:25]
+    return pose_1, pose_2, pose_3, intrctn_1, intrctn_2, intrctn_3, intrctn_4
+
+
+def get_label_from_action(action, person_num):
+    """action (B, MAX, 27), person_num list -> 7 lists (pose 1-3, interaction 1-4) of per-sample (n_b, k) labels (:174-221)."""
+    full = _labels(action)
+    return tuple([t[i, :person_num[i]] for i in range(action.shape[0])] for t in full)
+
+
+def get_label_from_action_batched(action, n):
+    """The same for a batch whose scenes all hold n actors: 7 tensors (B, n, k)."""
+    return _labels(action[:, :n])

@@ -97,6 +97,7 @@ def make_batch(seed, n_clips, n_frames, n_actors, n_points, height, width, devic
     """Synthetic batch on `device`: dict of tensors (see module docstring for the meaning)."""
     sc = S.scene_batch(seed, n_clips * n_frames, n_actors, n_points, num_boxes=n_actors + 1, height=height, width=width)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+    lab = S.scene_labels(seed + 3, n_clips * n_frames, n_actors, num_boxes=n_actors + 1)
     rng = np.random.default_rng(seed + 1)
     boxes2d = np.zeros((n_clips, n_actors + 1, 4), np.float32)
     for b in range(n_clips):
@@ -107,6 +108,9 @@ def make_batch(seed, n_clips, n_frames, n_actors, n_points, height, width, devic
         "points": t(sc["points"]),                                                # (B*T, P, 4)
         "bboxes3d": t(sc["bboxes3d"]),                                            # (B*T, A+1, 7)
         "person_id": t(sc["person_id"]),                                          # (B*T, A+1)
+        "social_group_id": t(lab["social_group_id"]),                             # (B*T, A+1) int64, -1 padded
+        "action": t(lab["action"]),                                               # (B*T, A+1, 27)
+        "social_group_activity": t(lab["social_group_activity"]),                 # (B*T, A+1, 27)
         "n_clips": n_clips, "n_frames": n_frames, "n_actors": n_actors,
     }
 
@@ -240,8 +244,20 @@ def voxelize_batch(points, dataset, max_points=5, max_voxels=40000):
 
 
 def synthetic_loss(outputs):
-    """Scalar over all 16 outputs so that every trainable parameter receives a gradient."""
+    """Scalar over all 16 outputs so that every trainable parameter receives a gradient (round-1 placeholder objective;
+    kept for tests that need a label-free scalar)."""
     return sum((o.float() ** 2).mean() for o in outputs)
+
+
+def reference_loss(outputs, batch):
+    """The reference's training objective (train_func.py:166-256, Loss = "L_total" as train_func.py:553 selects it: weighted
+    adjacency BCE + individual pose CE / interaction BCE + social-group pose / interaction BCE) on synthetic annotations,
+    evaluated on the device without a Python loop over scenes (losses.mgar_losses_uniform).  Every frame-scene is one sample;
+    the per-sample terms are summed over the scenes, which is what the reference accumulates at its BATCH_SIZE 1
+    (train_func.py:260-269).  As in the reference, the cardinality head is not part of L_total and receives no gradient."""
+    from . import losses
+    return losses.mgar_losses_uniform(outputs, batch["social_group_id"], batch["action"], batch["social_group_activity"],
+                                      batch["n_actors"], Loss="L_total", reference_semantics=False)["L_total"]
 
 
 class TrainStep:
@@ -254,7 +270,9 @@ class TrainStep:
     (no DDP wrapper: its hooks cannot live inside a captured backward), then Adam."""
 
     def __init__(self, n_actors, n_points, device, gat=True, route="pointnet2", ddp=False, lr=1e-3, seed=2023,
-                 manual_allreduce=False):
+                 manual_allreduce=False, loss="reference"):
+        assert loss in ("reference", "synthetic")
+        self.loss_kind = loss
         torch.manual_seed(seed)  # the reference seeds 2023 (train_func.py:45-47)
         self.model = ClipModel(n_actors, n_points, gat, route).to(device)
         self.model.train()
@@ -265,6 +283,8 @@ class TrainStep:
             dev_ids = [device.index] if device.type == "cuda" else None
             self.model = DDP(self.model, device_ids=dev_ids, find_unused_parameters=False, gradient_as_bucket_view=True,
                              bucket_cap_mb=64)
+        if ddp and manual_allreduce:
+            self._sync_from_rank0()
         self.params = [p for p in self.model.parameters() if p.requires_grad]
         # train_func.py:552 Adam(lr=1e-3); on the device the fused implementation (a handful of launches instead of ~30)
         self.opt = torch.optim.Adam(self.params, lr=lr, fused=(device.type == "cuda") or None)
@@ -276,9 +296,23 @@ class TrainStep:
     def _forward_backward(self, batch):
         self.opt.zero_grad(set_to_none=True)
         out = self.model(batch)
-        loss = synthetic_loss(out)
+        loss = self._loss_of(out, batch)
         loss.backward()
         return loss.detach()
+
+    def _loss_of(self, out, batch):
+        return reference_loss(out, batch) if self.loss_kind == "reference" else synthetic_loss(out)
+
+    def _sync_from_rank0(self):
+        """Flat-all-reduce data parallelism: every rank starts from rank 0's parameters and buffers (DistributedDataParallel
+        does this itself).  BatchNorm running statistics then evolve per rank -- they are never exchanged, as under the
+        reference's nn.DataParallel, whose replicas' buffer updates are discarded except replica 0's (train_func.py:512)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t, src=0)
 
     def _exchange_gradients(self):
         """One all-reduce(SUM)/world over all gradients, flattened (~119 MB fp32 per step)."""
@@ -287,6 +321,13 @@ class TrainStep:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
+        # parameters outside the objective (the cardinality head under L_total; conv_out / shared_fc of the voxel route, unused
+        # downstream as in the reference) have no gradient on ANY rank: the layout below is the same everywhere.  A parameter
+        # that received a gradient on some ranks only would desynchronise the collective, so the set is pinned at the first step.
+        have = tuple(p.grad is not None for p in self.params)
+        if getattr(self, "_grad_layout", None) is None:
+            self._grad_layout = have
+        assert have == self._grad_layout, "the set of parameters with gradients changed between steps"
         grads = [p.grad for p in self.params if p.grad is not None]
         flat = torch._utils._flatten_dense_tensors(grads)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
@@ -318,7 +359,7 @@ class TrainStep:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self.model(batch)
-            loss = synthetic_loss(out)
+            loss = self._loss_of(out, batch)
             loss.backward()
         self.graph, self._loss = graph, loss.detach()
         self._graph_grads = [p.grad for p in self.params]   # the buffers every replay writes (graph-private pool)
