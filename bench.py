@@ -22,9 +22,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# MIOpen's user find-db (which solver is fastest for each I3D convolution shape on gfx950), recorded once with
-# torch.backends.cudnn.benchmark = True and shipped with the package; must be set before MIOpen initialises.
-os.environ.setdefault("MIOPEN_USER_DB_PATH", os.path.join(ROOT, "multimodal_gar_amd", "miopen_db"))
+import multimodal_gar_amd  # noqa: E402,F401  -- points MIOPEN_USER_DB_PATH at a scratch copy of the shipped find-db before MIOpen starts
 
 import torch  # noqa: E402
 
@@ -93,7 +91,7 @@ def parse():
 # single stream, so that every kernel has the chip to itself between its two events -- and the headline number
 # is not perturbed by ~3 000 event records per step.
 # --------------------------------------------------------------------------------------------
-MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel")
+MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel", "stem_conv3d_kernel")
 PAIR_KERNELS = ("fps_kernel", "ball_query_kernel", "three_nn_kernel")   # (query, point) scans: VALU-bound, pair evaluations of 8 flop
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # rocprofv3 --pmc passes, see profiles/README.md
 

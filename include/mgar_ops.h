@@ -323,6 +323,15 @@ int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *
 int mgar_maxpool3d_same_fwd(const float *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh,
                             int sw, float *y, void *stream);
 
+/* The first convolution of Inception-I3D (model/backbone.py:305-307 ``Conv3d_1a_7x7``: Unit3D(3 -> 64, kernel [7,7,7],
+ * stride (2,2,2), TF "same" padding :168-172, no bias) as a direct implicit GEMM on the fp32 MFMA: padding handled in the
+ * kernel (no padded copy), NCDHW in and out (no layout transposes).  x (N, 3, T, H, W), w (64, 3, 7, 7, 7) ->
+ * y (N, 64, ceil(T/2), ceil(H/2), ceil(W/2)).  w_packed: caller-allocated scratch of
+ * mgar_stem_conv3d_workspace_floats() floats.  Forward only (I3D is frozen in MGAR-net). */
+int mgar_stem_conv3d_workspace_floats(void);
+int mgar_stem_conv3d_fwd(const float *x, int N, int T, int H, int W, const float *w, float *w_packed, float *y,
+                         void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).
@@ -515,6 +524,9 @@ int mgar_maxpool3d_same_fwd_bf16(const void *x, int NC, int T, int H, int W, int
 int mgar_roi_align_fwd_bf16(const void *input, int N, int C, int H, int W, const float *rois, int K,
                             int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,
                             void *out, void *stream);
+/* x, y (w and the accumulation fp32) */
+int mgar_stem_conv3d_fwd_bf16(const void *x, int N, int T, int H, int W, const float *w, float *w_packed, void *y,
+                              void *stream);
 /* feats, pooled */
 int mgar_voxel_roi_pool_fwd_bf16(int M, int nsample, int C, const float *xyz, const float *new_xyz, const void *feats,
                                  int ld_f, const int *idx, const float *w_pos, const float *mean, const float *invstd,

@@ -2,6 +2,51 @@
 and the host-side mirror of the reference's model / pcdet interfaces."""
 import os as _os
 
-# MIOpen's user find-db for the I3D convolution shapes on gfx950 (consulted when the caller enables
-# torch.backends.cudnn.benchmark); must be in the environment before MIOpen initialises.
-_os.environ.setdefault("MIOPEN_USER_DB_PATH", _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db"))
+
+def _setup_miopen_user_db():
+    """MIOpen's user find-db for the I3D convolution shapes on gfx950 (consulted when the caller enables
+    torch.backends.cudnn.benchmark), shipped READ-ONLY in miopen_db/.  MIOpen rewrites its user db while it runs, so the
+    shipped files are copied once into a per-user, per-rank scratch directory and MIOPEN_USER_DB_PATH points there: the
+    tracked files are never dirtied, read-only installs work, and ranks of one node do not write the same files.
+    Must happen before MIOpen initialises; an explicit MIOPEN_USER_DB_PATH in the environment wins.
+
+    What the db can and cannot do (measured, profiles/README.md round 2): MIOpen re-validates a find-db record against
+    its KERNEL cache and regenerates it ("Find-db regenerating") when the solver's binaries are not cached -- always the
+    case on a fresh machine -- so the first pass of a new process on a fresh box still searches (33-42 s for the I3D
+    shapes); with a warm kernel cache the records are used as they are.  The steady-state solver choice is the same
+    either way (13.3 ms per clip; immediate mode without a search: 18-20 ms)."""
+    if "MIOPEN_USER_DB_PATH" in _os.environ:
+        return
+    import shutil
+    import tempfile
+    src = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+    rank = _os.environ.get("LOCAL_RANK", "0")
+    dst = _os.path.join(tempfile.gettempdir(), "mgar_miopen_db_u%d_r%s" % (_os.getuid(), rank))
+    try:
+        _os.makedirs(dst, exist_ok=True)
+        for f in _os.listdir(src):
+            if not _os.path.exists(_os.path.join(dst, f)):
+                shutil.copy(_os.path.join(src, f), _os.path.join(dst, f))
+        _os.environ["MIOPEN_USER_DB_PATH"] = dst
+    except OSError:
+        pass       # no writable scratch: MIOpen falls back to its default user-db location
+
+
+def miopen_db_matches_runtime():
+    """True if the shipped find-db was recorded with the MIOpen build that is running (the file names carry the version);
+    logs a warning otherwise -- the records are then ignored silently by MIOpen."""
+    import glob
+    import logging
+    import torch
+    src = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+    names = [_os.path.basename(p) for p in glob.glob(_os.path.join(src, "*.ufdb.txt"))]
+    ver = getattr(torch.backends.cudnn, "version", lambda: None)()      # MIOpen version as an integer, e.g. 3005000
+    ok = ver is None or any("%d_%d_%d" % (ver // 1000000, (ver // 1000) % 1000, ver % 1000) in n for n in names)
+    if not ok:
+        logging.getLogger("multimodal_gar_amd").warning(
+            "the shipped MIOpen find-db (%s) was recorded with a different MIOpen build than the running one (%s): it is ignored",
+            names, ver)
+    return ok
+
+
+_setup_miopen_user_db()

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -72,6 +72,8 @@ _PROTOS = {
     "mgar_pointwise_dw_workspace_floats": [_I, _I, _I, _I],
     "mgar_pointwise_conv_dw_act": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "mgar_pointwise_conv_fwd": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
+    "mgar_stem_conv3d_workspace_floats": [],
+    "mgar_stem_conv3d_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_maxpool3d_same_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
@@ -99,7 +101,7 @@ for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_que
            "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
            "mgar_bn_act_fwd_grouped", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
            "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_stack",
-           "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd"):
+           "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]
 BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 

@@ -1,0 +1,197 @@
+// stem_conv.hip -- the first convolution of Inception-I3D (Conv3d_1a_7x7: 3 -> 64 channels, 7x7x7, stride 2, TF-"same"
+// padding) as a direct implicit GEMM on the exact-fp32 MFMA, for gfx950.
+//
+// Reference: model/backbone.py:134-206 (Unit3D: dynamic "same" padding + nn.Conv3d(bias=False)), instance :305-307
+// (``Conv3d_1a_7x7``, kernel [7,7,7], stride (2,2,2)); the convolution itself is torch / cuDNN there (MIOpen here).
+//
+// Why a kernel: with C_in = 3 the library's implicit-GEMM convolution runs at 39 % of the fp32 MFMA peak and is the
+// largest single kernel of a training step (31.6 of 268 ms at config c3: 29.1 ms CK kernel + NCDHW <-> NDHWC transposes
+// of its 1.3 GB input and 4.7 GB output + the F.pad copy of the asymmetric "same" padding).  Here:
+//   * D[co][position] = sum_k W[co][k] * patch[k][position] with M = 64 output channels as the MFMA rows and 32
+//     consecutive output columns (wo) as the MFMA columns, so every accumulator register is 128 contiguous bytes of the
+//     NCDHW output: no transposes, coalesced stores;
+//   * K = 3 * 7 * 7 * 7 = 1029 is walked as 21 (kt, c_in) slabs of 49 (kh, kw) taps (padded to 50 = 25 k-steps of
+//     v_mfma_f32_32x32x2_f32); a slab needs a (21 rows x 69 columns) input patch for the workgroup's 8 x 32 output tile
+//     and a 50 x 64 weight block: both are staged in LDS, double-buffered, the next slab's global loads in flight under
+//     the current slab's 100 MFMAs per wave; slabs whose input plane lies in the temporal padding are skipped;
+//   * the input patch is stored de-interleaved by column parity, so the stride-2 reads of a stride-2 convolution
+//     (column 2 wo + kw) are unit-stride in LDS: conflict-free;
+//   * padding is handled by the patch loader (zeros): no padded copy of the input.
+// Work per workgroup: 256 outputs x 64 channels; 4 waves x (2 channel blocks x 2 output rows) accumulators.
+// fp32 accumulation in tap order (kt, c_in, kh, kw): the result is an fp32 FMA chain like the library's, in a different
+// order (parity test: 1e-5 relative).  T = payload type of input / output (float or bf16_t); weights fp32.
+#include "common.hpp"
+#include "payload.hpp"
+
+namespace mgar {
+
+typedef float __attribute__((ext_vector_type(16))) f32x16;
+
+constexpr int SCV_K = 7, SCV_S = 2, SCV_CIN = 3, SCV_COUT = 64;
+constexpr int SCV_TH = 8, SCV_TW = 32;                                   // output tile (ho x wo) per workgroup
+constexpr int SCV_IH = SCV_S * (SCV_TH - 1) + SCV_K;                      // 21 input rows
+constexpr int SCV_IW = SCV_S * (SCV_TW - 1) + SCV_K;                      // 69 input columns
+constexpr int SCV_IWH = (SCV_IW + 1) / 2;                                 // 35 per column parity
+constexpr int SCV_TAPS = 50;                                              // 49 (kh, kw) taps + 1 zero tap
+constexpr int SCV_IN_FLOATS = SCV_IH * 2 * SCV_IWH;                       // 1470
+constexpr int SCV_W_FLOATS = SCV_TAPS * SCV_COUT;                         // 3200
+constexpr int SCV_IN_PER_THREAD = (SCV_IH * SCV_IW + 255) / 256;          // 6
+constexpr int SCV_W_PER_THREAD = SCV_W_FLOATS / 4 / 256 + 1;              // 4 float4 (800 float4 over 256 threads)
+
+struct StemArgs {
+    int N, T, H, W, To, Ho, Wo, pt, ph, pw;   // front paddings of the TF "same" mode
+};
+
+// wp: weights packed as [kt][c_in][tap (50)][co (64)], tap = kh * 7 + kw, tap 49 = 0
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_conv3d_kernel(const T *__restrict__ x, const float *__restrict__ wp, StemArgs a,
+                                                             T *__restrict__ y) {
+    __shared__ float s_in[2][SCV_IN_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_w[2][SCV_W_FLOATS];
+    const int tiles_w = (a.Wo + SCV_TW - 1) / SCV_TW;
+    const int bx = blockIdx.x % tiles_w, by = blockIdx.x / tiles_w;
+    const int to = blockIdx.y, n = blockIdx.z;
+    const int wo0 = bx * SCV_TW, ho0 = by * SCV_TH;
+    const int hbase = SCV_S * ho0 - a.ph, wbase = SCV_S * wo0 - a.pw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, h = lane >> 5;
+
+    // the (kt, c) slabs whose input plane exists: kt in [kt_lo, kt_hi)
+    const int t0 = SCV_S * to - a.pt;
+    const int kt_lo = max(0, -t0), kt_hi = min(SCV_K, a.T - t0);
+    const int nslab = max(0, kt_hi - kt_lo) * SCV_CIN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+
+    float pin[SCV_IN_PER_THREAD];
+    float4 pw4[SCV_W_PER_THREAD];
+    auto fetch = [&](int slab) {                       // global -> registers
+        const int kt = kt_lo + slab / SCV_CIN, c = slab % SCV_CIN;
+        const T *plane = x + (((size_t)n * SCV_CIN + c) * a.T + (t0 + kt)) * a.H * a.W;
+#pragma unroll
+        for (int u = 0; u < SCV_IN_PER_THREAD; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int ir = e / SCV_IW, ic = e - ir * SCV_IW;
+            const int hh = hbase + ir, ww = wbase + ic;
+            pin[u] = (e < SCV_IH * SCV_IW && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? Payload<T>::ld(plane + (size_t)hh * a.W + ww) : 0.f;
+        }
+        const float4 *wsrc = reinterpret_cast<const float4 *>(wp + (size_t)(kt * SCV_CIN + c) * SCV_W_FLOATS);
+#pragma unroll
+        for (int u = 0; u < SCV_W_PER_THREAD; ++u) {
+            const int e = threadIdx.x + u * 256;
+            pw4[u] = e < SCV_W_FLOATS / 4 ? wsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto stash = [&](int buf) {                        // registers -> LDS (input de-interleaved by column parity)
+#pragma unroll
+        for (int u = 0; u < SCV_IN_PER_THREAD; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int ir = e / SCV_IW, ic = e - ir * SCV_IW;
+            if (e < SCV_IH * SCV_IW) s_in[buf][(ir * 2 + (ic & 1)) * SCV_IWH + (ic >> 1)] = pin[u];
+        }
+#pragma unroll
+        for (int u = 0; u < SCV_W_PER_THREAD; ++u) {
+            const int e = threadIdx.x + u * 256;
+            if (e < SCV_W_FLOATS / 4) reinterpret_cast<float4 *>(s_w[buf])[e] = pw4[u];
+        }
+    };
+
+    if (nslab > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int slab = 0; slab < nslab; ++slab) {
+        const int buf = slab & 1;
+        if (slab + 1 < nslab) fetch(slab + 1);         // in flight under the MFMAs below
+        const float *ti = s_in[buf], *tw = s_w[buf];
+#pragma unroll 5
+        for (int s = 0; s < SCV_TAPS / 2; ++s) {
+            const int tap = 2 * s + h;
+            int kh = tap / SCV_K, kw = tap - kh * SCV_K;
+            if (tap >= SCV_K * SCV_K) { kh = 0; kw = 0; }                  // the zero tap: any valid address
+            const float wa0 = tw[tap * SCV_COUT + l], wa1 = tw[tap * SCV_COUT + 32 + l];
+            const int col = (kw & 1) * SCV_IWH + l + (kw >> 1);
+            const float b0 = ti[(SCV_S * (2 * wave + 0) + kh) * 2 * SCV_IWH + col];
+            const float b1 = ti[(SCV_S * (2 * wave + 1) + kh) * 2 * SCV_IWH + col];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, b0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa0, b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (slab + 1 < nslab) stash(buf ^ 1);          // the other buffer: its last readers passed the barrier of slab - 1
+        __syncthreads();
+    }
+    // D[row = co][col = l = wo]: every accumulator register is 32 consecutive output columns of one channel
+    const int wo = wo0 + l;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int ho = ho0 + 2 * wave + nb;
+        if (ho >= a.Ho || wo >= a.Wo) continue;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Payload<T>::st(y + ((((size_t)n * SCV_COUT + co) * a.To + to) * a.Ho + ho) * a.Wo + wo, acc[mb][nb][r]);
+            }
+    }
+}
+
+// (64, 3, 7, 7, 7) -> [kt][c][tap 50][co 64]
+__global__ void stem_pack_weights_kernel(const float *__restrict__ w, float *__restrict__ wp) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= SCV_K * SCV_CIN * SCV_W_FLOATS) return;
+    const int co = e % SCV_COUT, tap = (e / SCV_COUT) % SCV_TAPS, c = (e / SCV_W_FLOATS) % SCV_CIN, kt = e / (SCV_W_FLOATS * SCV_CIN);
+    float v = 0.f;
+    if (tap < SCV_K * SCV_K) {
+        const int kh = tap / SCV_K, kw = tap - kh * SCV_K;
+        v = w[((((size_t)co * SCV_CIN + c) * SCV_K + kt) * SCV_K + kh) * SCV_K + kw];
+    }
+    wp[e] = v;
+}
+
+template <typename T>
+static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *w, float *w_packed, T *y, void *stream) {
+    MGAR_REQUIRE(N >= 0 && Tn > 0 && H > 0 && W > 0, "stem_conv3d_fwd: bad sizes");
+    if (N == 0) return MGAR_OK;
+    MGAR_REQUIRE(x && w && w_packed && y, "stem_conv3d_fwd: null pointer");
+    auto front = [](int size) {   // TF "same" for kernel 7, stride 2 (model/backbone.py:168-172)
+        const int total = size % SCV_S == 0 ? SCV_K - SCV_S : SCV_K - size % SCV_S;
+        return (total > 0 ? total : 0) / 2;
+    };
+    StemArgs a{N, Tn, H, W, (Tn + 1) / 2, (H + 1) / 2, (W + 1) / 2, front(Tn), front(H), front(W)};
+    MGAR_REQUIRE(a.To <= 65535 && N <= 65535, "stem_conv3d_fwd: T or N too large");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SCV_W_FLOATS, 256)), dim3(256), 0, st, w, w_packed);
+    const int tiles = ((a.Wo + SCV_TW - 1) / SCV_TW) * ((a.Ho + SCV_TH - 1) / SCV_TH);
+    const double outs = (double)N * a.To * a.Ho * a.Wo;
+    {
+        KtScope kt(KT_STEM_CONV, st, (double)sizeof(T) * ((double)N * SCV_CIN * Tn * H * W + outs * SCV_COUT),
+                   2.0 * outs * SCV_COUT * SCV_CIN * SCV_K * SCV_K * SCV_K);
+        hipLaunchKernelGGL(stem_conv3d_kernel<T>, dim3(tiles, a.To, N), dim3(256), 0, st, x, (const float *)w_packed, a, y);
+    }
+    return check_launch("stem_conv3d_fwd: launch failed");
+}
+
+}  // namespace mgar
+
+using namespace mgar;
+
+#define SCV_API extern "C" __attribute__((visibility("default")))
+
+// x (N, 3, T, H, W), w (64, 3, 7, 7, 7) -> y (N, 64, ceil(T/2), ceil(H/2), ceil(W/2)); w_packed: caller-allocated scratch of
+// mgar_stem_conv3d_workspace_floats() floats (the weights re-laid out for the kernel, rewritten on every call).
+SCV_API int mgar_stem_conv3d_workspace_floats(void) { return SCV_K * SCV_CIN * SCV_W_FLOATS; }
+SCV_API int mgar_stem_conv3d_fwd(const float *x, int N, int T, int H, int W, const float *w, float *w_packed, float *y, void *stream) {
+    return stem_conv_impl<float>(x, N, T, H, W, w, w_packed, y, stream);
+}
+SCV_API int mgar_stem_conv3d_fwd_bf16(const void *x, int N, int T, int H, int W, const float *w, float *w_packed, void *y, void *stream) {
+    return stem_conv_impl<bf16_t>((const bf16_t *)x, N, T, H, W, w, w_packed, (bf16_t *)y, stream);
+}

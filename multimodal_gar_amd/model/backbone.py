@@ -83,9 +83,33 @@ class Unit3D(nn.Module):
     def compute_pad(self, dim, s):
         return sum(_same_pad_1d(s, self._kernel_shape[dim], self._stride[dim]))
 
+    stem_kernel = True     # 3 -> 64, 7x7x7, stride 2 on the device: csrc/stem_conv.hip instead of pad + library convolution
+
+    def _stem_conv(self, x):
+        """The I3D stem (Conv3d_1a_7x7) on csrc/stem_conv.hip: "same" padding inside the kernel, NCDHW in and out; or None."""
+        c = self.conv3d
+        if not (self.stem_kernel and x.is_cuda and x.dim() == 5 and x.dtype in (torch.float32, torch.bfloat16)
+                and c.in_channels == 3 and c.out_channels == 64 and self._kernel_shape == (7, 7, 7) and self._stride == (2, 2, 2)
+                and c.bias is None and not (torch.is_grad_enabled() and (x.requires_grad or c.weight.requires_grad))):
+            return None
+        from .. import _lib as L
+        if torch.is_autocast_enabled() and x.dtype == torch.float32:
+            x = x.to(torch.get_autocast_dtype('cuda'))
+        x = x.contiguous()
+        n, _, t, h, w = x.shape
+        y = torch.empty((n, 64, (t + 1) // 2, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device)
+        wp = torch.empty((L.raw("mgar_stem_conv3d_workspace_floats"),), dtype=torch.float32, device=x.device)
+        wf = c.weight.detach().float().contiguous()
+        L.payload_call("mgar_stem_conv3d_fwd", x.dtype, L.pptr(x, x.dtype), n, t, h, w, L.fptr(wf), L.fptr(wp), L.pptr(y, x.dtype),
+                       L.stream_of(x))
+        return y
+
     def forward(self, x):
         pads = _same_pads(x.shape[2:], self._kernel_shape, self._stride)
-        if all(f == b for f, b in pads):
+        stem = self._stem_conv(x)
+        if stem is not None:
+            x = stem
+        elif all(f == b for f, b in pads):
             x = F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
         else:
             x = self.conv3d(F.pad(x, _as_fpad(pads)))

@@ -394,3 +394,32 @@ def test_kernel_timers_bracket_launches():
     assert t["bn_partial_kernel"][2] == 3 * 4 * x.numel() and t["bn_apply_kernel"][2] == 3 * 8 * x.numel()
     assert 0 <= t["bn_partial_kernel"][0] < 500 and 0 <= t["bn_apply_kernel"][0] < 500   # ms; bounds only
     assert L.kernel_timers() == {}            # reset by the read above; nothing recorded while disabled
+
+
+@pytest.mark.parametrize("shape", [(2, 15, 64, 96), (1, 7, 37, 53), (1, 16, 50, 130), (3, 3, 16, 32)])
+def test_stem_conv3d_kernel_vs_padded_library_convolution(shape):
+    """csrc/stem_conv.hip (I3D Conv3d_1a_7x7: 3 -> 64, 7x7x7, stride 2, TF "same" padding inside the kernel) against
+    F.pad + conv3d in float64, odd / even sizes (front pads 3 vs 2), partial tiles; bf16 payload = rounded fp32 result."""
+    import torch.nn.functional as F
+    from multimodal_gar_amd.model.backbone import Unit3D
+    n, t, h, w = shape
+    torch.manual_seed(3)
+    u = Unit3D(3, 64, [7, 7, 7], stride=(2, 2, 2), padding=(3, 3, 3), use_batch_norm=False, activation_fn=None).cuda()
+    x = torch.randn(n, 3, t, h, w, device="cuda")
+    with torch.no_grad():
+        got = u(x)
+        pads = []
+        for size in (w, h, t):                               # F.pad order: last dim first
+            total = 5 if size % 2 == 0 else 6
+            pads += [total // 2, total - total // 2]
+        want = F.conv3d(F.pad(x.double(), pads), u.conv3d.weight.double(), stride=2)
+        assert got.shape == want.shape == (n, 64, (t + 1) // 2, (h + 1) // 2, (w + 1) // 2)
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item(), err
+        u.stem_kernel = False
+        lib = u(x)                                           # the library route of the same module
+        assert (lib - got).abs().max().item() <= 1e-4 * want.abs().max().item()
+        u.stem_kernel = True
+        xb = x.to(torch.bfloat16)
+        gb = u(xb)
+        assert gb.dtype == torch.bfloat16 and torch.equal(gb, u(xb.float()).to(torch.bfloat16))
