@@ -160,7 +160,7 @@ def kernel_rooflines(step, batch, frames, n_points, clips_local=None):
             row["pair_evals_per_s"] = flops / 8.0 / (ms * 1e-3)
             row["valu_frac"] = flops / (ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS
         res.append(row)
-    lib_rows, lib_totals = lib_ops.table()
+    lib_rows, lib_totals = lib_ops.table(top=int(os.environ.get("MGAR_BENCH_LIB_ROWS", "12")))   # rows per class (conv / gemm / other)
     res += lib_rows
     res.sort(key=lambda r: -r["ms_per_step"])
     for r in res:
