@@ -29,10 +29,12 @@ KERNELS = {
     "rowmajor_dw_kernel": "mgar::rowmajor_dw_kernel", "maxpool3d_same_kernel": "mgar::maxpool3d_same",
     "fps_kernel": "mgar::fps_", "ball_query_kernel": "mgar::ball_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
     "three_interp_fwd": "mgar::three_interp_batch_fwd", "three_interp_bwd": "mgar::three_interp_batch_bwd",
-    "query_group_fwd": "_fwd_kernel(int, int, int, int, float const*", "query_group_bwd": "mgar::qg_",
+    "query_group_fwd": "mgar::qg_", "query_group_bwd": "mgar::qg_",
+    "stem_conv3d_kernel": "mgar::stem_conv3d_kernel", "voxel_roi_pool_fwd": "mgar::vrp_fwd_kernel", "voxel_roi_pool_bwd": "mgar::vrp_bwd_kernel",
 }
 WIDE_READERS = {"bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel",
                 "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel", "pointwise_dw_kernel", "maxpool3d_same_kernel"}
+# (stem_conv3d_kernel reads its input patches with 4-byte loads: uncalibrated, like the gather kernels)
 
 
 def per_kernel(path, counter):
@@ -42,7 +44,7 @@ def per_kernel(path, counter):
             continue
         n = r["Kernel_Name"]
         for key, sub in KERNELS.items():
-            if sub in n and not (key == "query_group_bwd" and "bwd" not in n) and not (key == "query_group_fwd" and "qg_" not in n):
+            if sub in n and not (key == "query_group_bwd" and "bwd" not in n) and not (key == "query_group_fwd" and "_fwd_kernel" not in n):
                 t = tot[key]
                 t[0] += float(r["Counter_Value"]) * 1024.0
                 t[1] += 1
@@ -55,6 +57,7 @@ def main():
     out = {"unit": "bytes per launch (HBM-side, FETCH_SIZE [x2 for float4 streaming readers] + WRITE_SIZE, KiB * 1024)",
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 1 at config c3",
            "clips_per_gpu": int(sys.argv[3]) if len(sys.argv) > 3 else 8,   # bench.py attaches the figures only to this per-rank batch
+           "commit": sys.argv[4] if len(sys.argv) > 4 else "unknown",
            # sha256[:16] of the .hip file each kernel was compiled from at measurement time: bench.py attaches a figure only
            # while the source is unchanged
            "per_launch_bytes": {}, "source_sha16": {}, "detail": {}}
