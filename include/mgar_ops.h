@@ -237,6 +237,21 @@ int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const floa
 int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
                                     const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf,
                                     int zf_ld, void *stream);
+/* The same gradient WITHOUT float atomics and bit-reproducible (replaces the scatter of the reference's
+ * group_points_grad_kernel_stack, pcdet/ops/pointnet2/pointnet2_stack/src/group_points_gpu.cu:15-46, for C <= 64):
+ *   1. inverse_count: col_src[col] = source row of column col = (query, slot), -1 for an empty ball; counts[row] += 1
+ *      (counts zero-filled by the caller);
+ *   2. the caller scans counts into offsets (N + 1 entries, exclusive);
+ *   3. inverse_fill: list[offsets[row] ...] = the columns that reference row (cursor: N zero-filled ints);
+ *   4. bwd_rows: grad_zf[row][0..C) = sum of g_t[col][0..C) over the row's columns in ascending column order;
+ *      g_t is the ROW-MAJOR gradient (M * nsample, C); rows nobody references are not written; `list` may be reordered and
+ *      `scratch` (M * nsample ints; col_src is free by then) overwritten. */
+int mgar_query_group_stack_inverse_count(int B, int M, int nsample, const int *idx, const int *new_xyz_batch_cnt,
+                                         const int *xyz_batch_cnt, int *col_src, int *counts, void *stream);
+int mgar_query_group_stack_inverse_fill(long long total, const int *col_src, const int *offsets, int *cursor, int *list,
+                                        void *stream);
+int mgar_query_group_stack_bwd_rows(int N, int C, long long total, const int *offsets, int *list, int *scratch,
+                                    const float *g_t, float *grad_zf, int zf_ld, void *stream);
 
 /* Weight gradient of that projection on the exact-fp32 MFMA, stacked (row-major) operands:
  *   dw[o][i] = sum_n a[n*lda + o] * f[n*ldf + i]      a (N,Co) = grad_zf, f (N,Ci) = features
@@ -284,6 +299,11 @@ int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, co
 int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
                     float *dbeta, float *dx, void *stream);
+/* mgar_bn_act_bwd with the input gradient written ROW-MAJOR, dx_t (B*P, C), C <= 64: the layout the atomic-free stack
+ * grouping backward (mgar_query_group_stack_bwd_rows) gathers from. */
+int mgar_bn_act_bwd_rowmajor(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                             const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
+                             float *dbeta, float *dx_t, void *stream);
 int mgar_bn_act_maxpool_bwd(const float *dpool, const float *pooled, const unsigned char *arg, const float *x,
                             const float *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd,
                             const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta,

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -67,6 +67,10 @@ _PROTOS = {
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_act_bwd_rowmajor": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_query_group_stack_inverse_count": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_stack_inverse_fill": [_LL, _P, _P, _P, _P, _P],
+    "mgar_query_group_stack_bwd_rows": [_I, _I, _LL, _P, _P, _P, _P, _P, _I, _P],
     "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_pointwise_conv_dw": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "mgar_pointwise_dw_workspace_floats": [_I, _I, _I, _I],

@@ -42,12 +42,27 @@ def _train_stats(x3, bn):
     return mean, invstd
 
 
+ROWMAJOR_GRAD_MAX_CHANNELS = 64   # csrc/bn_act.hip: bn_bwd_apply_t_kernel transposes through a 64 x 65 LDS tile
+
+
+def _bwd_rowmajor(dy, x3, mean, invstd, gamma, beta, relu, ws, dgamma, dbeta):
+    """BatchNorm [+ ReLU] backward whose input gradient is stored ROW-MAJOR, (B * P, C), and handed to autograd as the
+    (B, C, P) transposed VIEW of that memory: the consumer that asked for it (the atomic-free stacked grouping backward,
+    pointnet2_stack/pointnet2_utils.py) reads whole rows; anything else sees an ordinary strided tensor."""
+    b, c, p = x3.shape
+    dx_t = torch.empty((b, p, c), dtype=torch.float32, device=x3.device)
+    L.call("mgar_bn_act_bwd_rowmajor", L.fptr(dy), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+           int(relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx_t), L.stream_of(x3))
+    return dx_t.permute(0, 2, 1)
+
+
 class _BnAct(Function):
     """y = [relu](batch_norm_train(x)) for x (B, C, P); saves x (not y) for the backward."""
 
     @staticmethod
-    def forward(ctx, x3, gamma, beta, mean, invstd, relu):
+    def forward(ctx, x3, gamma, beta, mean, invstd, relu, rowmajor_grad=False):
         b, c, p = x3.shape
+        ctx.rowmajor = bool(rowmajor_grad) and x3.dtype == torch.float32 and c <= ROWMAJOR_GRAD_MAX_CHANNELS
         y = torch.empty_like(x3)
         dt = x3.dtype
         L.payload_call("mgar_bn_act_fwd", dt, L.pptr(x3, dt), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
@@ -61,15 +76,17 @@ class _BnAct(Function):
     def backward(ctx, dy):
         x3, gamma, beta, mean, invstd = ctx.saved_tensors
         b, c, p = x3.shape
-        dx = torch.empty_like(x3)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
         # every tensor whose pointer is passed stays bound to a name until the call returns: a
         # temporary freed mid-expression can be handed out again by the caching allocator
         dt = x3.dtype
         dy_c, ws = dy.contiguous().to(dt), _workspace(x3, b, c, p)
+        if ctx.rowmajor:
+            return _bwd_rowmajor(dy_c, x3, mean, invstd, gamma, beta, ctx.relu, ws, dgamma, dbeta), dgamma, dbeta, None, None, None, None
+        dx = torch.empty_like(x3)
         L.payload_call("mgar_bn_act_bwd", dt, L.pptr(dy_c, dt), L.pptr(x3, dt), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
                        L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.pptr(dx, dt), L.stream_of(x3))
-        return dx, dgamma, dbeta, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None
 
 
 class _BnActMaxPool(Function):
@@ -112,8 +129,9 @@ class _BnActConv(Function):
     gradient kernel (csrc/pointwise_dw.hip); only the pre-BN x is saved."""
 
     @staticmethod
-    def forward(ctx, x3, gamma, beta, mean, invstd, relu, w):
+    def forward(ctx, x3, gamma, beta, mean, invstd, relu, w, rowmajor_grad=False):
         b, c, p = x3.shape
+        ctx.rowmajor = bool(rowmajor_grad) and x3.dtype == torch.float32 and c <= ROWMAJOR_GRAD_MAX_CHANNELS
         cout = w.shape[0]
         w = w.contiguous()
         dt = x3.dtype
@@ -143,18 +161,20 @@ class _BnActConv(Function):
         ga = torch.empty_like(x3)
         L.call("mgar_pointwise_conv_fwd", L.fptr(gy), b, cout, p, L.fptr(w), 1, c, c, None, None, None, None, 0,
                L.fptr(ga), st)
-        dx = torch.empty_like(x3)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = _workspace(x3, b, c, p)
+        if ctx.rowmajor:
+            return _bwd_rowmajor(ga, x3, mean, invstd, gamma, beta, ctx.relu, ws, dgamma, dbeta), dgamma, dbeta, None, None, None, dw, None
+        dx = torch.empty_like(x3)
         L.call("mgar_bn_act_bwd", L.fptr(ga), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
                L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), st)
-        return dx, dgamma, dbeta, None, None, None, dw
+        return dx, dgamma, dbeta, None, None, None, dw, None
 
 
 FUSED_CONV_MAX_CHANNELS = 64   # csrc/pointwise_fwd.hip: Cout <= 64 in both directions
 
 
-def bn_act_conv(x, bn, relu, conv):
+def bn_act_conv(x, bn, relu, conv, rowmajor_grad=False):
     """conv(relu?(bn(x))) for a bias-free kernel-size-1 ``conv`` in one fused step, or None if the
     shapes are outside the fused kernel (the caller then runs bn_act and the GEMM separately)."""
     if not (x.is_cuda and x.dtype in _PAYLOADS and bn.training and x.dim() >= 3 and conv.bias is None):
@@ -168,7 +188,7 @@ def bn_act_conv(x, bn, relu, conv):
         return None
     mean, invstd = _stats(x3, bn)
     gamma, beta = _affine(bn, c, x.device)
-    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, _f32(conv.weight).view(cout, c))
+    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, _f32(conv.weight).view(cout, c), rowmajor_grad)
     return y.view(x.shape[0], cout, *x.shape[2:])
 
 
@@ -184,14 +204,14 @@ def _stats(x3, bn):
     return _f32(bn.running_mean), torch.rsqrt(_f32(bn.running_var) + bn.eps)
 
 
-def bn_act(x, bn, relu):
+def bn_act(x, bn, relu, rowmajor_grad=False):
     """[relu](bn(x)) for x (B, C, ...) contiguous on the device; ``bn`` is the nn.BatchNormNd module."""
     x3 = x.contiguous().flatten(2) if x.dim() > 2 else x.contiguous().unsqueeze(-1)
     if not bn.training and torch.is_grad_enabled() and x.requires_grad:
         return None  # eval-mode backward: let the caller take the plain torch path
     mean, invstd = _stats(x3, bn)
     gamma, beta = _affine(bn, x3.shape[1], x.device)
-    return _BnAct.apply(x3, gamma, beta, mean, invstd, relu).view(x.shape)
+    return _BnAct.apply(x3, gamma, beta, mean, invstd, relu, rowmajor_grad).view(x.shape)
 
 
 def bn_act_per_sample(x, bn, relu):

@@ -384,6 +384,36 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const T *__res
     }
 }
 
+// The same with a ROW-MAJOR result dx_t (B*P, C): the layout the stacked query-and-group backward gathers row by row
+// (csrc/query_group.hip, qg_stack_bwd_rows_kernel).  A workgroup owns 64 columns of all C <= 64 channels: coalesced
+// channel-major reads, an LDS transpose, coalesced row-major writes.  grid (ceil(P / 64), B)
+template <bool RELU>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_t_kernel(const float *__restrict__ dy, const float *__restrict__ x, int C,
+                                                                    int P, const float *__restrict__ mean,
+                                                                    const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, const float *__restrict__ coef,
+                                                                    float *__restrict__ dx_t) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.y, p0 = blockIdx.x * 64;
+    const int np = min(64, P - p0);
+    for (int e = threadIdx.x; e < C * 64; e += BN_THREADS) {
+        const int c = e >> 6, pl = e & 63;
+        if (pl >= np) continue;
+        const size_t o = ((size_t)b * C + c) * P + p0 + pl;
+        const float mu = mean[c], is = invstd[c];
+        const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+        const float k = is * g;
+        const float xv = x[o];
+        float d = dy[o];
+        const float xh = (xv - mu) * is;
+        if (RELU && !((xv - mu) * k + bt > 0.f)) d = 0.f;
+        tile[pl][c] = k * (d - coef[2 * c] - xh * coef[2 * c + 1]);
+    }
+    __syncthreads();
+    float *dst = dx_t + ((size_t)b * P + p0) * C;
+    for (int e = threadIdx.x; e < np * C; e += BN_THREADS) dst[e] = tile[e / C][e % C];
+}
+
 // after a fused max-pool: 4 B read + 4 B written per element (+ 9 B per group, cached).
 // lanes run along the flat (m, s) index, 4 elements per lane.  grid (ceil(M*NS/(256*4)), B*C)
 template <bool RELU, typename T>
@@ -669,3 +699,31 @@ BN_BOTH(mgar_bn_act_maxpool_bwd,
          float *dgamma, float *dbeta, void *dx, void *stream),
         bn_act_maxpool_bwd_impl<float>(dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, gamma, relu, workspace, dgamma, dbeta, dx, stream),
         bn_act_maxpool_bwd_impl<bf16_t>((cbf)dpool, (cbf)pooled, arg, (cbf)x, (cbf)xarg, B, C, M, nsample, mean, invstd, gamma, relu, workspace, dgamma, dbeta, (mbf)dx, stream))
+
+// bn_act_bwd with the input gradient written ROW-MAJOR: dx_t (B*P, C) instead of dx (B, C, P).  fp32, C <= 64.
+BN_API int mgar_bn_act_bwd_rowmajor(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                                    const float *gamma, const float *beta, int relu, float *workspace, float *dgamma, float *dbeta,
+                                    float *dx_t, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_bwd_rowmajor: bad sizes");
+    if (C > 64) {
+        set_error("bn_act_bwd_rowmajor: C <= 64");
+        return MGAR_EUNSUPPORTED;
+    }
+    if ((long long)B * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx_t, "bn_act_bwd_rowmajor: null pointer");
+    MGAR_REQUIRE(B <= 65535, "bn_act_bwd_rowmajor: B > 65535");
+    const int nchunk = bn_nchunk(B, P);
+    float *coef = workspace + (size_t)2 * C * nchunk;
+    hipStream_t st = (hipStream_t)stream;
+    { KtScope kt(KT_BN_BWD_REDUCE, st, 8.0 * (double)B * C * P);
+    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, float>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, float>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
+    dim3 grid(ceil_div(P, 64), B);
+    { KtScope kt(KT_BN_BWD_APPLY, st, 12.0 * (double)B * C * P);
+    if (relu) hipLaunchKernelGGL(bn_bwd_apply_t_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx_t);
+    else hipLaunchKernelGGL(bn_bwd_apply_t_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx_t);
+    }
+    return check_launch("bn_act_bwd_rowmajor: launch failed");
+}

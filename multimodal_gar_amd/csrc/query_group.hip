@@ -219,6 +219,175 @@ __global__ __launch_bounds__(256) void qg_stack_bwd_kernel(int B, int M, int C, 
     }
 }
 
+// ---- stack backward without float atomics: inverted index + owner-computes ------------------------------------------------
+// The atomic scatter above runs at the chip's float-atomic rate (~1.3 TB/s of added bytes; 1.7 ms per scale of the RoI-grid
+// lift at config c3) and its sums depend on the arrival order.  Here every source row is summed by ONE owner in a fixed order:
+//   1. qg_inv_count_kernel : source row of every column (col_src) + per-row reference counts (integer atomics: exact, cheap);
+//   2. an exclusive scan of the counts (the caller's cumsum) -> offsets;
+//   3. qg_inv_fill_kernel  : list[offsets[row] + cursor++] = column  (order inside a row's list is arbitrary here);
+//   4. qg_stack_bwd_rows_kernel: a half-wave per source row sorts its list (rank sort: the summation order becomes the
+//      column order, whatever step 3 did), then adds the listed rows of the ROW-MAJOR gradient g_t (M*nsample, C) -- one
+//      contiguous 4*C-byte read per entry -- and stores its feature-gradient row once.  Rows nobody references are not
+//      touched (the caller zero-fills).
+__global__ __launch_bounds__(256) void qg_inv_count_kernel(int B, int M, int nsample, const int *__restrict__ idx,
+                                                           const int *__restrict__ q_cnt, const int *__restrict__ p_cnt,
+                                                           int *__restrict__ col_src, int *__restrict__ counts) {
+    __shared__ int seg_q_end, seg_p_start;
+    const long long total = (long long)M * nsample;
+    const long long col0 = (long long)blockIdx.x * 256;
+    if (threadIdx.x == 0) {
+        const Segment sg = find_segment((int)(col0 / nsample), B, q_cnt, p_cnt);
+        seg_q_end = sg.a_start + q_cnt[sg.bs];
+        seg_p_start = sg.b_start;
+    }
+    __syncthreads();
+    const long long col = col0 + threadIdx.x;
+    if (col >= total) return;
+    const int m = (int)(col / nsample);
+    int src = -1;
+    if (idx[(size_t)m * nsample] >= 0) {
+        const int p_start = m < seg_q_end ? seg_p_start : find_segment(m, B, q_cnt, p_cnt).b_start;
+        src = p_start + idx[col];
+        atomicAdd(counts + src, 1);
+    }
+    col_src[col] = src;
+}
+
+__global__ __launch_bounds__(256) void qg_inv_fill_kernel(long long total, const int *__restrict__ col_src,
+                                                          const int *__restrict__ offsets, int *__restrict__ cursor,
+                                                          int *__restrict__ list) {
+    const long long col = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= total) return;
+    const int src = col_src[col];
+    if (src < 0) return;
+    list[offsets[src] + atomicAdd(cursor + src, 1)] = (int)col;
+}
+
+constexpr int QR_CAP = 512;           // list entries a half-wave sorts in LDS at once (8 half-waves: 16 KB per workgroup)
+constexpr int QR_PER_LANE = QR_CAP / 32;
+
+__device__ __forceinline__ void qr_wave_sync() {            // LDS hand-over between the lanes of one wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// buf[0, len) ascending, len <= QR_CAP, by one half-wave.  The entries are distinct (column numbers), so the ranks are a
+// permutation; every lane keeps its entries in registers while it counts, then all write back in place.
+__device__ __forceinline__ void qr_rank_sort(int *buf, int len, int lane) {
+    int e[QR_PER_LANE], r[QR_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < QR_PER_LANE; ++i) {
+        const int p = i * 32 + lane;
+        e[i] = p < len ? buf[p] : 0x7fffffff;
+        r[i] = 0;
+    }
+    for (int j = 0; j < len; ++j) {
+        const int v = buf[j];                                // broadcast read
+#pragma unroll
+        for (int i = 0; i < QR_PER_LANE; ++i) r[i] += v < e[i];
+    }
+    qr_wave_sync();
+#pragma unroll
+    for (int i = 0; i < QR_PER_LANE; ++i)
+        if (i * 32 + lane < len) buf[r[i]] = e[i];
+    qr_wave_sync();
+}
+
+// grid ceil(N / 8): 8 half-waves per workgroup, one source row each.  No workgroup barrier: the half-waves are independent.
+// The summation order is a fixed function of the row's SORTED column list, whatever order the fill kernel left:
+//   L <= QR_CAP : one LDS sort, four interleaved partial sums;
+//   longer      : chunks of QR_CAP sorted in LDS and written back, then a merge over the chunk heads (sequential sum); the head
+//                 positions live in LDS, or for more than QR_CAP chunks in the row's own stretch of `scratch` (col_src, which
+//                 nobody reads any more): a single row with > 262 144 references is slow (~1 us per reference) but correct.
+__global__ __launch_bounds__(256) void qg_stack_bwd_rows_kernel(int N, int C, const int *__restrict__ offsets, int *list,
+                                                                int *scratch, const float *__restrict__ g_t,
+                                                                float *__restrict__ grad_features, int ld) {
+    __shared__ int lds[8][QR_CAP];
+    const int hw = threadIdx.x >> 5, lane = threadIdx.x & 31;
+    const int row = blockIdx.x * 8 + hw;
+    if (row >= N) return;
+    const int start = offsets[row], L = offsets[row + 1] - start;
+    if (L == 0) return;
+    int *buf = lds[hw];
+    int *lst = list + start;
+    const bool c0 = lane < C, c1 = lane + 32 < C;
+    float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};     // channels lane and lane + 32
+    if (L <= QR_CAP) {
+        for (int i = lane; i < L; i += 32) buf[i] = lst[i];
+        qr_wave_sync();
+        qr_rank_sort(buf, L, lane);
+        int k = 0;
+        for (; k + 4 <= L; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *g = g_t + (size_t)buf[k + u] * C;
+                if (c0) a0[u] += g[lane];
+                if (c1) a1[u] += g[lane + 32];
+            }
+        }
+        for (; k < L; ++k) {
+            const float *g = g_t + (size_t)buf[k] * C;
+            if (c0) a0[0] += g[lane];
+            if (c1) a1[0] += g[lane + 32];
+        }
+    } else {
+        const int nchunk = (L + QR_CAP - 1) / QR_CAP;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int base = ch * QR_CAP, len = min(QR_CAP, L - base);
+            for (int i = lane; i < len; i += 32) buf[i] = lst[base + i];
+            qr_wave_sync();
+            qr_rank_sort(buf, len, lane);
+            for (int i = lane; i < len; i += 32) lst[base + i] = buf[i];
+            qr_wave_sync();
+        }
+        __threadfence();
+        int *heads = nchunk <= QR_CAP ? buf : scratch + start;              // head position of chunk ch: touched by lane ch % 32 only
+        for (int ch = lane; ch < nchunk; ch += 32) heads[ch] = 0;
+        int which = -1, cur = 0x7fffffff;
+        auto lane_min = [&]() {
+            cur = 0x7fffffff;
+            which = -1;
+            for (int ch = lane; ch < nchunk; ch += 32) {
+                const int pos = heads[ch], len = min(QR_CAP, L - ch * QR_CAP);
+                if (pos < len) {
+                    const int v = lst[ch * QR_CAP + pos];
+                    if (v < cur) {
+                        cur = v;
+                        which = ch;
+                    }
+                }
+            }
+        };
+        lane_min();
+        for (int k = 0; k < L; ++k) {
+            int best = cur;
+#pragma unroll
+            for (int d = 16; d >= 1; d >>= 1) best = min(best, __shfl_xor(best, d, 32));
+            if (cur == best && which >= 0) {
+                heads[which] += 1;
+                lane_min();
+            }
+            // compensated (Kahan) sum: a row this long would otherwise lose ~sqrt(L) ulps to the running total
+            const float *g = g_t + (size_t)best * C;
+            if (c0) {
+                const float y = g[lane] - a0[1], t = a0[0] + y;
+                a0[1] = (t - a0[0]) - y;
+                a0[0] = t;
+            }
+            if (c1) {
+                const float y = g[lane + 32] - a1[1], t = a1[0] + y;
+                a1[1] = (t - a1[0]) - y;
+                a1[0] = t;
+            }
+        }
+        a0[1] = a1[1] = 0.f;
+    }
+    float *dst = grad_features + (size_t)row * ld;
+    if (c0) dst[lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+    if (c1) dst[lane + 32] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+}
+
 constexpr int QG_LDS_MAX_FLOATS = 36864;
 
 }  // namespace mgar
@@ -383,4 +552,44 @@ QG_API int mgar_query_group_proj_stack_fwd_bf16(int B, int M, int C, int nsample
     MGAR_REQUIRE(wx && zf && y_out && zf_ld >= C, "query_group_proj_stack_fwd_bf16: null pointer or zf_ld < C");
     return qg_stack_fwd<bf16_t>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, (const bf16_t *)zf, zf_ld, wx, idx,
                                 (bf16_t *)rel_out, (bf16_t *)y_out, stream, "query_group_proj_stack_fwd_bf16: launch failed");
+}
+
+// ---- deterministic stack backward (no float atomics): see qg_stack_bwd_rows_kernel ---------------------------------------------
+// Step 1: col_src (M*nsample) int32 = global source row of every column (-1: empty ball), counts (N) += references
+// (counts zero-filled by the caller).  Step 3: list (sum counts) from offsets = exclusive scan of counts (N + 1 entries) and a
+// zero-filled cursor (N).  Step 4: grad_features (N, ld) rows with references are written, the others left alone; g_t is the
+// ROW-MAJOR gradient (M*nsample, C), C <= 64; `list` may come back reordered (long rows are sorted in place) and `scratch`
+// (M*nsample ints: pass col_src, which is dead by then) overwritten.
+QG_API int mgar_query_group_stack_inverse_count(int B, int M, int nsample, const int *idx, const int *new_xyz_batch_cnt,
+                                                const int *xyz_batch_cnt, int *col_src, int *counts, void *stream) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && nsample >= 0, "query_group_stack_inverse_count: negative size");
+    const long long total = (long long)M * nsample;
+    if (B == 0 || total == 0) return MGAR_OK;
+    MGAR_REQUIRE(idx && new_xyz_batch_cnt && xyz_batch_cnt && col_src && counts, "query_group_stack_inverse_count: null pointer");
+    hipLaunchKernelGGL(qg_inv_count_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, B, M, nsample, idx,
+                       new_xyz_batch_cnt, xyz_batch_cnt, col_src, counts);
+    return check_launch("query_group_stack_inverse_count: launch failed");
+}
+QG_API int mgar_query_group_stack_inverse_fill(long long total, const int *col_src, const int *offsets, int *cursor, int *list,
+                                               void *stream) {
+    MGAR_REQUIRE(total >= 0, "query_group_stack_inverse_fill: negative size");
+    if (total == 0) return MGAR_OK;
+    MGAR_REQUIRE(col_src && offsets && cursor && list, "query_group_stack_inverse_fill: null pointer");
+    hipLaunchKernelGGL(qg_inv_fill_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, col_src, offsets, cursor,
+                       list);
+    return check_launch("query_group_stack_inverse_fill: launch failed");
+}
+QG_API int mgar_query_group_stack_bwd_rows(int N, int C, long long total, const int *offsets, int *list, int *scratch,
+                                           const float *g_t, float *grad_features, int ld, void *stream) {
+    MGAR_REQUIRE(N >= 0 && C >= 1 && ld >= C && total >= 0, "query_group_stack_bwd_rows: bad sizes");
+    if (C > 64) {
+        set_error("query_group_stack_bwd_rows: C <= 64");
+        return MGAR_EUNSUPPORTED;
+    }
+    if (N == 0 || total == 0) return MGAR_OK;
+    MGAR_REQUIRE(offsets && list && scratch && g_t && grad_features, "query_group_stack_bwd_rows: null pointer");
+    KtScope kt(KT_QUERY_GROUP_BWD, (hipStream_t)stream, (double)total * (4.0 + 4.0 * C));
+    hipLaunchKernelGGL(qg_stack_bwd_rows_kernel, dim3(ceil_div(N, 8)), dim3(256), 0, (hipStream_t)stream, N, C, offsets, list, scratch,
+                       g_t, grad_features, ld);
+    return check_launch("query_group_stack_bwd_rows: launch failed");
 }

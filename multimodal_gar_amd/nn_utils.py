@@ -82,13 +82,15 @@ class PointwiseSequential(nn.Sequential):
 
     fuse_bn_conv = True
 
-    def _run(self, x, pool_last, start=0):
+    def _run(self, x, pool_last, start=0, rowmajor_input_grad=False):
         from . import bn_ops
         layers = list(self)
         i, n = start, len(layers)
         pooled = False
         while i < n:
             layer = layers[i]
+            # only the layer that consumes the input can hand its gradient back row-major
+            rm = rowmajor_input_grad and i == start and x.dim() == 4 and x.shape[0] == 1
             if _is_pointwise(layer):
                 x = conv1x1(layer, x)
                 i += 1
@@ -99,7 +101,7 @@ class PointwiseSequential(nn.Sequential):
                 nxt = i + (2 if relu else 1)
                 if nxt < n and _is_pointwise(layers[nxt]) and self.fuse_bn_conv:
                     # [BN -> ReLU -> next conv] in one pass; the activated tensor is never written
-                    y = bn_ops.bn_act_conv(x, layer, relu, layers[nxt])
+                    y = bn_ops.bn_act_conv(x, layer, relu, layers[nxt], rowmajor_grad=rm)
                     if y is not None:
                         x = y
                         i = nxt + 1
@@ -108,7 +110,7 @@ class PointwiseSequential(nn.Sequential):
                     y = bn_ops.bn_act_maxpool(x, layer, relu)
                     pooled = y is not None
                 if y is None:
-                    y = bn_ops.bn_act(x, layer, relu)
+                    y = bn_ops.bn_act(x, layer, relu, rowmajor_grad=rm)
                 if y is None:            # eval-mode backward etc.: plain torch
                     y = layer(x)
                     relu = False
@@ -122,9 +124,10 @@ class PointwiseSequential(nn.Sequential):
     def forward(self, x):
         return self._run(x, False)[0]
 
-    def forward_maxpool(self, x, start=0):
-        """(B, C, M, ns) -> (B, C', M): the MLP (from layer `start`) followed by a max over ns."""
-        y, pooled = self._run(x, True, start)
+    def forward_maxpool(self, x, start=0, rowmajor_input_grad=False):
+        """(B, C, M, ns) -> (B, C', M): the MLP (from layer `start`) followed by a max over ns.
+        ``rowmajor_input_grad``: the caller's backward prefers d x as (M * ns, C) rows (B = 1; see bn_ops._bwd_rowmajor)."""
+        y, pooled = self._run(x, True, start, rowmajor_input_grad)
         return y if pooled else y.max(dim=3).values
 
     def first_layer_foldable(self, c_in):

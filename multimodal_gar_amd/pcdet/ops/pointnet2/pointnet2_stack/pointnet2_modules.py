@@ -35,6 +35,10 @@ def build_local_aggregation_module(input_channels, config):
 class StackSAModuleMSG(nn.Module):
     """Reference: pointnet2_modules.py:30-112 (kaiming-normal convs, BN weight 1 / bias 0)."""
 
+    # the folded path's grouping backward without float atomics (csrc/query_group.hip, qg_stack_bwd_rows_kernel); False: the
+    # atomic scatter of round 1 (kept for the A/B in profiles/ and for C_k > 64)
+    rowmajor_grad = True
+
     def __init__(self, *, radii: List[float], nsamples: List[int], mlps: List[List[int]],
                  use_xyz: bool = True, pool_method='max_pool'):
         super().__init__()
@@ -85,7 +89,7 @@ class StackSAModuleMSG(nn.Module):
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if k in projected:
                 y0 = projected[k]
-                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1)
+                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1, rowmajor_input_grad=self.rowmajor_grad)
                 per_scale.append(x.squeeze(0).permute(1, 0))
                 continue
             assert features is None or features.dim() == 2, "channel-major features need the projected (foldable) path"

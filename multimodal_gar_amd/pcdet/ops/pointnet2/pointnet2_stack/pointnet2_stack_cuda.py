@@ -124,6 +124,27 @@ def query_group_proj_grad_wrapper(B, M, C, nsample, grad_y, idx_raw, new_xyz_bat
     return 1
 
 
+def query_group_proj_grad_rows_wrapper(B, M, C, nsample, grad_y_t, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, zf_ld=None,
+                                       zf_col=0):
+    """The gradient of query_group_proj_wrapper from a ROW-MAJOR grad_y_t (M * nsample, C): inverted index + one owner per
+    source row, no float atomics, bit-reproducible (csrc/query_group.hip, qg_stack_bwd_rows_kernel).  grad_zf zero-filled."""
+    import torch
+    zf_ld = C if zf_ld is None else zf_ld
+    n_rows, total = grad_zf.shape[0], M * nsample
+    dev, st = grad_zf.device, L.stream_of(grad_y_t)
+    col_src = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+    counts = torch.zeros((n_rows + 1,), dtype=torch.int32, device=dev)        # [0] stays 0: the scan below is exclusive
+    L.call("mgar_query_group_stack_inverse_count", B, M, nsample, L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt), L.iptr(xyz_batch_cnt),
+           L.iptr(col_src), counts.data_ptr() + 4, st)
+    offsets = torch.cumsum(counts, 0, dtype=torch.int32)
+    cursor = torch.zeros((max(n_rows, 1),), dtype=torch.int32, device=dev)
+    inv_list = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+    L.call("mgar_query_group_stack_inverse_fill", total, L.iptr(col_src), L.iptr(offsets), L.iptr(cursor), L.iptr(inv_list), st)
+    L.call("mgar_query_group_stack_bwd_rows", n_rows, C, total, L.iptr(offsets), L.iptr(inv_list), L.iptr(col_src), L.fptr(grad_y_t),
+           grad_zf.data_ptr() + 4 * zf_col, zf_ld, st)
+    return 1
+
+
 def rowmajor_dw(a, f):
     """a (N, Co), f (N, Ci) row-major contiguous -> a^T f (Co, Ci) on csrc/rowmajor_dw.hip."""
     import torch

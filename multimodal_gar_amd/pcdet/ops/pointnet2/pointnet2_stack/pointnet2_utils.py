@@ -223,7 +223,17 @@ class _FusedQueryGroupProjMSG(Function):
         col = 0
         for k, (c, nsample) in enumerate(zip(chans, nsamples)):
             idx, rel = saved[2 * k], saved[2 * k + 1]
-            gy = grad_ys[k].contiguous()
+            gy = grad_ys[k]
+            if gy.stride() == (1, c) and c <= 64 and gy.dtype == torch.float32:
+                # the MLP handed the gradient back as rows (M * nsample, C_k) (nn_utils.forward_maxpool(rowmajor_input_grad=True)):
+                # owner-computes gather, no float atomics, bit-reproducible
+                gy_t = gy.t()
+                pointnet2.query_group_proj_grad_rows_wrapper(n_samples, n_query, c, nsample, gy_t, idx, new_xyz_batch_cnt,
+                                                             xyz_batch_cnt, grad_zf, zf_ld=ld, zf_col=col)
+                grad_wx.append(pointnet2.rowmajor_dw(gy_t, rel.float().t().contiguous()))       # (C_k, 3)
+                col += c
+                continue
+            gy = gy.contiguous()
             pointnet2.query_group_proj_grad_wrapper(n_samples, n_query, c, nsample, gy, idx, new_xyz_batch_cnt, xyz_batch_cnt,
                                                     grad_zf, zf_ld=ld, zf_col=col)
             grad_wx.append(pointwise_dw(rel.unsqueeze(0), gy.unsqueeze(0)))                    # (C_k, 3)

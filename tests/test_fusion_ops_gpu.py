@@ -396,7 +396,8 @@ def test_kernel_timers_bracket_launches():
     assert L.kernel_timers() == {}            # reset by the read above; nothing recorded while disabled
 
 
-@pytest.mark.parametrize("shape", [(2, 15, 64, 96), (1, 7, 37, 53), (1, 16, 50, 130), (3, 3, 16, 32)])
+@pytest.mark.parametrize("shape", [(2, 15, 64, 96), (1, 7, 37, 53), (1, 16, 50, 130), (3, 3, 16, 32), (1, 2, 64, 96), (2, 1, 20, 20), (1, 4, 64, 96),
+                                   (8, 2, 64, 96)])
 def test_stem_conv3d_kernel_vs_padded_library_convolution(shape):
     """csrc/stem_conv.hip (I3D Conv3d_1a_7x7: 3 -> 64, 7x7x7, stride 2, TF "same" padding inside the kernel) against
     F.pad + conv3d in float64, odd / even sizes (front pads 3 vs 2), partial tiles; bf16 payload = rounded fp32 result."""

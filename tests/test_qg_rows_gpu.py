@@ -1,0 +1,168 @@
+"""The stacked query-and-group backward WITHOUT float atomics (csrc/query_group.hip: qg_inv_count / qg_inv_fill /
+qg_stack_bwd_rows_kernel) and the BatchNorm backward that feeds it rows (csrc/bn_act.hip: bn_bwd_apply_t_kernel).
+
+Oracle: the scatter-add of the reference's group_points_grad_kernel_stack
+(pcdet/ops/pointnet2/pointnet2_stack/src/group_points_gpu.cu:15-46) restated in numpy float64 (np.add.at); the bar is
+1e-5 of the gradient scale AND bit-identical results from run to run (the atomic kernel gives neither guarantee)."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from param_fill import fill_deterministic  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, counts_p, counts_q, nsample, C, empty_every=0):
+    """idx in the raw ball-query convention: local indices into the sample's points; a row whose slot 0 is -1 is an empty ball."""
+    rng = np.random.default_rng(seed)
+    M = int(sum(counts_q))
+    idx = np.zeros((M, nsample), np.int32)
+    m0 = 0
+    for npts, nq in zip(counts_p, counts_q):
+        idx[m0:m0 + nq] = rng.integers(0, npts, (nq, nsample))
+        m0 += nq
+    if empty_every:
+        idx[::empty_every, 0] = -1
+    g = rng.standard_normal((C, M * nsample)).astype(np.float32)
+    return idx, g
+
+
+def _oracle(idx, g, counts_p, counts_q, nsample):
+    n = int(sum(counts_p))
+    C = g.shape[0]
+    out = np.zeros((n, C), np.float64)
+    p_start = np.repeat(np.concatenate([[0], np.cumsum(counts_p)[:-1]]), counts_q)
+    live = idx[:, 0] >= 0
+    src = (p_start[:, None] + idx)[live].reshape(-1)
+    cols = (np.arange(idx.shape[0])[:, None] * nsample + np.arange(nsample)[None, :])[live].reshape(-1)
+    np.add.at(out, src, g.astype(np.float64).T[cols])
+    return out
+
+
+CASES = [  # (points per sample, queries per sample, nsample, C, ld, col, empty_every)
+    ((700, 650), (90, 81), 16, 32, 32, 0, 7),          # short lists (LDS sort path)
+    ((40, 3), (300, 200), 16, 24, 56, 24, 5),          # lists of ~100 and ~1000 entries: LDS path and the chunk-merge path
+    ((2,), (3000,), 32, 64, 64, 0, 0),                 # two rows with ~48 000 references each: many chunks per row
+    ((500,), (64,), 8, 7, 16, 3, 0),                   # odd channel count, strided destination
+    ((1,), (9000,), 32, 5, 5, 0, 0),                   # one row, 288 000 references: past the merge path (selection)
+]
+
+
+@pytest.mark.parametrize("counts_p,counts_q,nsample,C,ld,col,empty_every", CASES)
+def test_rows_backward_matches_scatter_add_oracle_and_is_reproducible(counts_p, counts_q, nsample, C, ld, col, empty_every):
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as P
+    idx, g = _case(3, counts_p, counts_q, nsample, C, empty_every)
+    want = _oracle(idx, g, counts_p, counts_q, nsample)
+    n, M = int(sum(counts_p)), int(sum(counts_q))
+    d_idx = torch.from_numpy(idx).cuda()
+    pc = torch.tensor(counts_p, dtype=torch.int32, device="cuda")
+    qc = torch.tensor(counts_q, dtype=torch.int32, device="cuda")
+    g_t = torch.from_numpy(np.ascontiguousarray(g.T)).cuda()                       # (M * nsample, C)
+    runs = []
+    for _ in range(3):
+        out = torch.full((n, ld), 0.0, device="cuda")
+        P.query_group_proj_grad_rows_wrapper(len(counts_p), M, C, nsample, g_t, d_idx, qc, pc, out, zf_ld=ld, zf_col=col)
+        runs.append(out.cpu().numpy())
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), "not bit-reproducible"
+    got = runs[0][:, col:col + C]
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 1e-5 * scale, (np.abs(got - want).max(), scale)
+    untouched = np.delete(runs[0], np.s_[col:col + C], axis=1)
+    assert not untouched.size or np.all(untouched == 0), "wrote outside its columns"
+    # the atomic kernel of round 1 on the same data (channel-major gradient): same sums up to rounding order
+    out = torch.zeros((n, ld), device="cuda")
+    P.query_group_proj_grad_wrapper(len(counts_p), M, C, nsample, torch.from_numpy(g).cuda(), d_idx, qc, pc, out, zf_ld=ld, zf_col=col)
+    assert np.abs(out.cpu().numpy()[:, col:col + C] - want).max() <= 2e-4 * scale
+
+
+def test_rows_backward_empty_inputs():
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as P
+    pc = torch.tensor([5], dtype=torch.int32, device="cuda")
+    qc = torch.tensor([0], dtype=torch.int32, device="cuda")
+    out = torch.zeros((5, 8), device="cuda")
+    P.query_group_proj_grad_rows_wrapper(1, 0, 8, 16, torch.zeros((0, 8), device="cuda"), torch.zeros((0, 16), dtype=torch.int32, device="cuda"),
+                                         qc, pc, out)
+    assert out.abs().sum().item() == 0
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("B,C,P", [(1, 32, 70000), (3, 17, 1000), (1, 64, 4099), (2, 1, 64)])
+def test_bn_backward_rowmajor_is_the_transposed_channel_major_result(B, C, P, relu):
+    from multimodal_gar_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    x = (torch.randn(B, C, P, generator=g) * 2 + 0.5).cuda()
+    dy = torch.randn(B, C, P, generator=g).cuda()
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).cuda(), torch.randn(C, generator=g).cuda()
+    mean = x.mean((0, 2)).contiguous()
+    invstd = torch.rsqrt(x.var((0, 2), unbiased=False) + 1e-5).contiguous()
+    res = []
+    for name in ("mgar_bn_act_bwd", "mgar_bn_act_bwd_rowmajor"):
+        ws = torch.empty((L.raw("mgar_bn_workspace_floats", B, C, P),), device="cuda")
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dx = torch.empty((B, C, P) if name.endswith("bwd") else (B, P, C), device="cuda")
+        L.call(name, L.fptr(dy), L.fptr(x), B, C, P, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), int(relu), L.fptr(ws),
+               L.fptr(dg), L.fptr(db), L.fptr(dx), L.stream_of(x))
+        res.append((dx if name.endswith("bwd") else dx.permute(0, 2, 1), dg, db))
+    for a, b in zip(*res):
+        assert torch.equal(a.contiguous(), b.contiguous())
+    # and the channel-major kernel itself against torch autograd in float64
+    x64 = x.double().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(x64, None, None, gamma.double(), beta.double(), True, 0.0, 1e-5)
+    (torch.relu(y) if relu else y).backward(dy.double())
+    err = (res[1][0].double() - x64.grad).abs().max().item()
+    assert err <= 2e-4 * x64.grad.abs().max().item() + 1e-6
+
+
+def test_stack_sa_module_rows_path_is_taken_and_matches_atomic_path(monkeypatch):
+    """StackSAModuleMSG (reference pointnet2_stack/pointnet2_modules.py:30-112) with the folded first layer: the rows path must
+    actually run for the scales whose MLP continues after the first BatchNorm, be bit-reproducible, and agree with the atomic
+    path (rowmajor_grad=False) to rounding."""
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_modules as MS
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as P
+    torch.manual_seed(4)
+    n = 3000
+    sx = (torch.rand(2 * n, 3) * torch.tensor([8.0, 8.0, 2.0])).cuda()
+    cnt = torch.tensor([n, n], dtype=torch.int32, device="cuda")
+    new_xyz = torch.cat([sx[:2200] + 0.03, sx[n:n + 2100] - 0.02, torch.tensor([[500., 500., 500.]], device="cuda")]).contiguous()
+    ncnt = torch.tensor([2200, 2101], dtype=torch.int32, device="cuda")
+    feats = torch.randn(2 * n, 40, device="cuda")
+    mixed = fill_deterministic(MS.StackSAModuleMSG(radii=[0.6, 1.2, 0.9], nsamples=[16, 16, 8], mlps=[[40, 32, 32], [40, 24, 32], [40, 16]]),
+                               seed=8).cuda().train()
+    deep = fill_deterministic(MS.StackSAModuleMSG(radii=[0.6, 1.2], nsamples=[16, 16], mlps=[[40, 32, 32], [40, 24, 32]]),
+                              seed=9).cuda().train()
+    calls = {"rows": 0, "atomic": 0}
+    rows, atomic = P.query_group_proj_grad_rows_wrapper, P.query_group_proj_grad_wrapper
+    monkeypatch.setattr(P, "query_group_proj_grad_rows_wrapper", lambda *a, **k: (calls.__setitem__("rows", calls["rows"] + 1), rows(*a, **k))[1])
+    monkeypatch.setattr(P, "query_group_proj_grad_wrapper", lambda *a, **k: (calls.__setitem__("atomic", calls["atomic"] + 1), atomic(*a, **k))[1])
+
+    def run(flag, mod=mixed):
+        m = copy.deepcopy(mod)
+        m.rowmajor_grad = flag
+        f = feats.clone().requires_grad_(True)
+        _, y = m(sx, cnt, new_xyz, ncnt, f)
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view(y.shape)).sum().backward()
+        return y.detach(), f.grad, [p.grad for p in m.parameters()]
+
+    a = run(True)
+    assert calls == {"rows": 2, "atomic": 1}, calls          # scale 3 ([40, 16]) pools straight after its BatchNorm: channel-major
+    # every scale on the rows path: the whole module backward is bit-reproducible (the atomic scatter of scale 3 above is not)
+    d, e = run(True, deep), run(True, deep)
+    assert torch.equal(d[1], e[1]) and all(torch.equal(p, q) for p, q in zip(d[2], e[2])), "rows path not bit-reproducible"
+    calls.update(rows=0, atomic=0)
+    c = run(False)
+    assert calls == {"rows": 0, "atomic": 3}
+    assert torch.equal(a[0], c[0])
+
+    def close(p, q, what):
+        err, scale = (p - q).abs().max().item(), q.abs().max().item()
+        assert err <= 2e-4 * scale + 1e-7, (what, err, scale)
+    close(a[1], c[1], "d features")
+    for i, (p, q) in enumerate(zip(a[2], c[2])):
+        close(p, q, "param %d" % i)
