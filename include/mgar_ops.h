@@ -237,21 +237,29 @@ int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const floa
 int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
                                     const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf,
                                     int zf_ld, void *stream);
-/* The same gradient WITHOUT float atomics and bit-reproducible (replaces the scatter of the reference's
+/* The same gradient WITHOUT atomics and bit-reproducible (replaces the scatter of the reference's
  * group_points_grad_kernel_stack, pcdet/ops/pointnet2/pointnet2_stack/src/group_points_gpu.cu:15-46, for C <= 64):
- *   1. inverse_count: col_src[col] = source row of column col = (query, slot), -1 for an empty ball; counts[row] += 1
- *      (counts zero-filled by the caller);
- *   2. the caller scans counts into offsets (N + 1 entries, exclusive);
- *   3. inverse_fill: list[offsets[row] ...] = the columns that reference row (cursor: N zero-filled ints);
- *   4. bwd_rows: grad_zf[row][0..C) = sum of g_t[col][0..C) over the row's columns in ascending column order;
- *      g_t is the ROW-MAJOR gradient (M * nsample, C); rows nobody references are not written; `list` may be reordered and
- *      `scratch` (M * nsample ints; col_src is free by then) overwritten. */
-int mgar_query_group_stack_inverse_count(int B, int M, int nsample, const int *idx, const int *new_xyz_batch_cnt,
-                                         const int *xyz_batch_cnt, int *col_src, int *counts, void *stream);
-int mgar_query_group_stack_inverse_fill(long long total, const int *col_src, const int *offsets, int *cursor, int *list,
-                                        void *stream);
-int mgar_query_group_stack_bwd_rows(int N, int C, long long total, const int *offsets, int *list, int *scratch,
-                                    const float *g_t, float *grad_zf, int zf_ld, void *stream);
+ *   1. inverse_index: a stable counting sort (histograms in LDS, no global atomics) of the (source row, column) pairs of the raw
+ *      ball-query result idx (M, nsample): list = the columns of every source row in ascending order; items = work items
+ *      int[4] (row, begin, length <= 256, parts of the row) -- capacity mgar_query_group_stack_inverse_items(), ZERO-FILLED
+ *      by the caller; row_item[row] = the row's first item, -1 if no column references it; workspace:
+ *      mgar_query_group_stack_inverse_workspace_ints(B, N, M * nsample) ints.  M * nsample < 2^31; at most 262 144 source
+ *      rows per sample (the caller guarantees it: the counts live on the device).
+ *   2. bwd_rows (workspace = the one inverse_index filled: part of the index): grad_zf[row][0..C) = sum of g_t[col][0..C)
+ *      over the row's columns, in list order; g_t is the ROW-MAJOR
+ *      gradient (M * nsample, C).  Rows nobody references are not written (hand in zeros).  part_rows: n_items * C floats of
+ *      scratch.  wx_part (optional, with xyz / new_xyz): ceil(n_items / 8) * C * 3 floats, ZERO-FILLED; summed over the first
+ *      axis they are d wx (C, 3) = sum_col g_t[col] (x) (xyz[row] - new_xyz[col / nsample]) -- the weight gradient of the
+ *      relative-coordinate half of the folded first layer, so the forward need not store rel_out for the backward. */
+long long mgar_query_group_stack_inverse_items(int B, int N, long long total);
+long long mgar_query_group_stack_inverse_workspace_ints(int B, int N, long long total);
+int mgar_query_group_stack_inverse_index(int B, int M, int nsample, int N, const int *idx, const int *new_xyz_batch_cnt,
+                                         const int *xyz_batch_cnt, int *workspace, int *list, int *items, int *row_item,
+                                         void *stream);
+int mgar_query_group_stack_bwd_rows(int n_items, int N, int C, int nsample, const int *workspace, const int *items,
+                                    const int *row_item, const int *list, const float *g_t, const float *xyz,
+                                    const float *new_xyz, float *grad_zf, int zf_ld, float *part_rows, float *wx_part,
+                                    long long total, void *stream);
 
 /* Weight gradient of that projection on the exact-fp32 MFMA, stacked (row-major) operands:
  *   dw[o][i] = sum_n a[n*lda + o] * f[n*ldf + i]      a (N,Co) = grad_zf, f (N,Ci) = features

@@ -68,9 +68,10 @@ _PROTOS = {
     "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_bn_act_bwd_rowmajor": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
-    "mgar_query_group_stack_inverse_count": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "mgar_query_group_stack_inverse_fill": [_LL, _P, _P, _P, _P, _P],
-    "mgar_query_group_stack_bwd_rows": [_I, _I, _LL, _P, _P, _P, _P, _P, _I, _P],
+    "mgar_query_group_stack_inverse_items": [_I, _I, _LL],
+    "mgar_query_group_stack_inverse_workspace_ints": [_I, _I, _LL],
+    "mgar_query_group_stack_inverse_index": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_query_group_stack_bwd_rows": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _LL, _P],
     "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_pointwise_conv_dw": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "mgar_pointwise_dw_workspace_floats": [_I, _I, _I, _I],
@@ -113,7 +114,7 @@ _fns = {}
 for _name, _args in _PROTOS.items():
     _fn = getattr(_cdll, _name)  # AttributeError here = the library is stale: rebuild it
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats")) else ctypes.c_int
+    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats", "_inverse_items", "_workspace_ints")) else ctypes.c_int
     _fns[_name] = _fn
 
 _cdll.mgar_abi_version.restype = ctypes.c_int

@@ -24,7 +24,7 @@ const char *const kKtNames[KT_COUNT] = {
     "fps_kernel", "ball_query_kernel", "three_nn_kernel", "three_interp_fwd", "three_interp_bwd", "query_group_fwd",
     "query_group_bwd", "bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel",
     "bn_bwd_apply_kernel", "bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel",
-    "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel", "voxel_roi_pool_fwd", "voxel_roi_pool_bwd", "stem_conv3d_kernel"};
+    "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel", "voxel_roi_pool_fwd", "voxel_roi_pool_bwd", "stem_conv3d_kernel", "query_group_inverse_index"};
 }  // namespace
 
 void kt_begin(int id, hipStream_t st) {

@@ -63,6 +63,12 @@ class StackSAModuleMSG(nn.Module):
                 nn.init.constant_(m.weight, 1.0)
                 nn.init.constant_(m.bias, 0)
 
+    def _rows_bwd(self, k):
+        """Scale k's grouping backward on the atomic-free rows path: its MLP must go on after the first BatchNorm + ReLU (else
+        that BatchNorm is fused with the max-pool and its backward is channel-major) with at most 64 channels."""
+        mlp = self.mlps[k]
+        return bool(self.rowmajor_grad) and len(mlp) > 3 and mlp[0].out_channels <= 64 and torch.is_grad_enabled()
+
     def forward(self, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features=None, empty_voxel_set_zeros=True):
         """-> (new_xyz (M, 3), new_features (M, sum_k mlps[k][-1])).
 
@@ -84,12 +90,12 @@ class StackSAModuleMSG(nn.Module):
                 ys = pointnet2_utils._FusedQueryGroupProjMSG.apply(
                     xyz, xyz_batch_cnt.int(), new_xyz, new_xyz_batch_cnt.int(), features,
                     tuple(self.groupers[k].radius for k in fold), tuple(self.groupers[k].nsample for k in fold),
-                    *[self.mlps[k][0].weight for k in fold])
+                    tuple(self._rows_bwd(k) for k in fold), *[self.mlps[k][0].weight for k in fold])
                 projected = dict(zip(fold, ys))
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if k in projected:
                 y0 = projected[k]
-                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1, rowmajor_input_grad=self.rowmajor_grad)
+                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1, rowmajor_input_grad=self._rows_bwd(k))
                 per_scale.append(x.squeeze(0).permute(1, 0))
                 continue
             assert features is None or features.dim() == 2, "channel-major features need the projected (foldable) path"

@@ -124,25 +124,41 @@ def query_group_proj_grad_wrapper(B, M, C, nsample, grad_y, idx_raw, new_xyz_bat
     return 1
 
 
+def query_group_inverse_index(B, M, nsample, N, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt):
+    """Inverted index of a raw ball-query result idx (M, nsample): for every source row the columns (query * nsample + slot)
+    that gather it, ascending, cut into work items (csrc/query_group.hip, qg_inv_*_kernel) -> (list, items, row_item, workspace)."""
+    import torch
+    dev, total = idx_raw.device, M * nsample
+    n_items = L.raw("mgar_query_group_stack_inverse_items", B, N, total)
+    inv_list = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
+    items = torch.zeros((max(n_items, 1), 4), dtype=torch.int32, device=dev)
+    row_item = torch.empty((max(N, 1),), dtype=torch.int32, device=dev)
+    ws = torch.empty((max(L.raw("mgar_query_group_stack_inverse_workspace_ints", B, N, total), 1),), dtype=torch.int32, device=dev)
+    L.call("mgar_query_group_stack_inverse_index", B, M, nsample, N, L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt), L.iptr(xyz_batch_cnt),
+           L.iptr(ws), L.iptr(inv_list), L.iptr(items), L.iptr(row_item), L.stream_of(idx_raw))
+    return inv_list, items, row_item, ws
+
+
 def query_group_proj_grad_rows_wrapper(B, M, C, nsample, grad_y_t, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, zf_ld=None,
-                                       zf_col=0):
+                                       zf_col=0, xyz=None, new_xyz=None, index=None):
     """The gradient of query_group_proj_wrapper from a ROW-MAJOR grad_y_t (M * nsample, C): inverted index + one owner per
-    source row, no float atomics, bit-reproducible (csrc/query_group.hip, qg_stack_bwd_rows_kernel).  grad_zf zero-filled."""
+    source row, no atomics, bit-reproducible (csrc/query_group.hip, qg_stack_bwd_rows_kernel).  grad_zf zero-filled by the
+    caller.  With xyz / new_xyz: also returns d wx (C, 3), the gradient of the relative-coordinate weights."""
     import torch
     zf_ld = C if zf_ld is None else zf_ld
     n_rows, total = grad_zf.shape[0], M * nsample
-    dev, st = grad_zf.device, L.stream_of(grad_y_t)
-    col_src = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
-    counts = torch.zeros((n_rows + 1,), dtype=torch.int32, device=dev)        # [0] stays 0: the scan below is exclusive
-    L.call("mgar_query_group_stack_inverse_count", B, M, nsample, L.iptr(idx_raw), L.iptr(new_xyz_batch_cnt), L.iptr(xyz_batch_cnt),
-           L.iptr(col_src), counts.data_ptr() + 4, st)
-    offsets = torch.cumsum(counts, 0, dtype=torch.int32)
-    cursor = torch.zeros((max(n_rows, 1),), dtype=torch.int32, device=dev)
-    inv_list = torch.empty((max(total, 1),), dtype=torch.int32, device=dev)
-    L.call("mgar_query_group_stack_inverse_fill", total, L.iptr(col_src), L.iptr(offsets), L.iptr(cursor), L.iptr(inv_list), st)
-    L.call("mgar_query_group_stack_bwd_rows", n_rows, C, total, L.iptr(offsets), L.iptr(inv_list), L.iptr(col_src), L.fptr(grad_y_t),
-           grad_zf.data_ptr() + 4 * zf_col, zf_ld, st)
-    return 1
+    inv_list, items, row_item, ws = index if index is not None else \
+        query_group_inverse_index(B, M, nsample, n_rows, idx_raw, new_xyz_batch_cnt, xyz_batch_cnt)
+    n_items = items.shape[0]
+    part_rows = torch.empty((n_items, C), dtype=torch.float32, device=grad_zf.device)
+    wx_part = torch.zeros(((n_items + 7) // 8, C, 3), dtype=torch.float32, device=grad_zf.device) if xyz is not None else None
+    L.call("mgar_query_group_stack_bwd_rows", n_items if total and n_rows else 0, n_rows, C, nsample, L.iptr(ws), L.iptr(items), L.iptr(row_item),
+           L.iptr(inv_list), L.fptr(grad_y_t), L.fptr(xyz) if xyz is not None else None, L.fptr(new_xyz) if xyz is not None else None,
+           grad_zf.data_ptr() + 4 * zf_col, zf_ld, L.fptr(part_rows), L.fptr(wx_part) if wx_part is not None else None, total,
+           L.stream_of(grad_y_t))
+    if wx_part is None:
+        return None
+    return wx_part.sum(0) if total and n_rows else torch.zeros((C, 3), dtype=torch.float32, device=grad_zf.device)
 
 
 def rowmajor_dw(a, f):

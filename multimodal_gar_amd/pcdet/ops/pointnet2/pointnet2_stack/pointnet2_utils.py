@@ -164,11 +164,14 @@ class _FusedQueryGroupProjMSG(Function):
     (csrc/query_group.hip, zf read with leading dimension sum C_k).  The weight gradient
     d W_f = grad_zf^T features runs on csrc/rowmajor_dw.hip.
 
-    apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, *weights)
-    with weights[k] (C_k, 3 + C) -> (y_1, ..., y_K), y_k (C_k, M * nsample_k) channel-major."""
+    apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, rows_bwd, *weights)
+    with weights[k] (C_k, 3 + C) -> (y_1, ..., y_K), y_k (C_k, M * nsample_k) channel-major.
+    rows_bwd[k]: the consumer of y_k hands its gradient back as rows (M * nsample_k, C_k) (nn_utils.forward_maxpool(
+    rowmajor_input_grad=True)); scale k then takes the atomic-free, bit-reproducible backward (qg_stack_bwd_rows_kernel),
+    which also forms d wx_k from the coordinates: the forward stores no relative coordinates for it."""
 
     @staticmethod
-    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, *weights):
+    def forward(ctx, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, rows_bwd, *weights):
         """features: (N, C) stacked rows, or (B, C, n) CHANNEL-MAJOR with n points in every sample (the layout the
         PointNet++ trunk produces: no transposed copy of the feature matrix is needed for the projection GEMM)."""
         n_samples, n_query = xyz_batch_cnt.shape[0], new_xyz.shape[0]
@@ -194,26 +197,27 @@ class _FusedQueryGroupProjMSG(Function):
         idxs = [torch.zeros((n_query, ns), dtype=torch.int32, device=xyz.device) for ns in nsamples]
         for radius, nsample, idx in zip(radii, nsamples, idxs):
             pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
-        for radius, nsample, w, c, idx in zip(radii, nsamples, ws, chans, idxs):
+        rows_bwd = tuple(bool(r) and c <= 64 and zf.dtype == torch.float32 for r, c in zip(rows_bwd, chans))
+        for radius, nsample, w, c, idx, rows in zip(radii, nsamples, ws, chans, idxs, rows_bwd):
             wx = w[:, :3].contiguous().float()
-            rel = _empty(xyz, (3, n_query * nsample), zf.dtype) if need_bwd else None
+            rel = _empty(xyz, (3, n_query * nsample), zf.dtype) if need_bwd and not rows else None
             y = _empty(xyz, (c, n_query * nsample), zf.dtype)
             pointnet2.query_group_proj_wrapper(n_samples, n_query, c, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
                                                zf, wx, idx, rel, y, zf_ld=ld, zf_col=col)
             outs.append(y)
             saved += [idx, rel if rel is not None else idx]
             col += c
-        ctx.save_for_backward(xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, *saved)
-        ctx.meta = (n_samples, n_query, tuple(chans), tuple(nsamples), tuple(w.shape for w in weights))
+        ctx.save_for_backward(xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, xyz, new_xyz, *saved)
+        ctx.meta = (n_samples, n_query, tuple(chans), tuple(nsamples), tuple(w.shape for w in weights), rows_bwd)
         return tuple(outs)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *grad_ys):
         from .....nn_utils import pointwise_dw
-        xyz_batch_cnt, new_xyz_batch_cnt, features, w_f = ctx.saved_tensors[:4]
-        saved = ctx.saved_tensors[4:]
-        n_samples, n_query, chans, nsamples, w_shapes = ctx.meta
+        xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, xyz, new_xyz = ctx.saved_tensors[:6]
+        saved = ctx.saved_tensors[6:]
+        n_samples, n_query, chans, nsamples, w_shapes, rows_bwd = ctx.meta
         ld = sum(chans)
         channel_major = features.dim() == 3
         n_rows = features.shape[0] * features.shape[2] if channel_major else features.shape[0]
@@ -224,13 +228,13 @@ class _FusedQueryGroupProjMSG(Function):
         for k, (c, nsample) in enumerate(zip(chans, nsamples)):
             idx, rel = saved[2 * k], saved[2 * k + 1]
             gy = grad_ys[k]
-            if gy.stride() == (1, c) and c <= 64 and gy.dtype == torch.float32:
-                # the MLP handed the gradient back as rows (M * nsample, C_k) (nn_utils.forward_maxpool(rowmajor_input_grad=True)):
-                # owner-computes gather, no float atomics, bit-reproducible
-                gy_t = gy.t()
-                pointnet2.query_group_proj_grad_rows_wrapper(n_samples, n_query, c, nsample, gy_t, idx, new_xyz_batch_cnt,
-                                                             xyz_batch_cnt, grad_zf, zf_ld=ld, zf_col=col)
-                grad_wx.append(pointnet2.rowmajor_dw(gy_t, rel.float().t().contiguous()))       # (C_k, 3)
+            if rows_bwd[k]:
+                # rows (M * nsample, C_k): as handed back by the MLP's first BatchNorm backward, or (any other producer) one
+                # transposing copy; owner-computes gather over the inverted index, no atomics, bit-reproducible
+                gy_t = gy.t() if gy.stride() == (1, c) else gy.t().contiguous()
+                grad_wx.append(pointnet2.query_group_proj_grad_rows_wrapper(
+                    n_samples, n_query, c, nsample, gy_t, idx, new_xyz_batch_cnt, xyz_batch_cnt, grad_zf, zf_ld=ld, zf_col=col,
+                    xyz=xyz, new_xyz=new_xyz))                                                 # (C_k, 3)
                 col += c
                 continue
             gy = gy.contiguous()
@@ -253,7 +257,7 @@ class _FusedQueryGroupProjMSG(Function):
         for c, gwx, shape in zip(chans, grad_wx, w_shapes):
             grad_ws.append(torch.cat([gwx, grad_wf[col:col + c]], 1).view(shape))
             col += c
-        return (None, None, None, None, grad_features, None, None, *grad_ws)
+        return (None, None, None, None, grad_features, None, None, None, *grad_ws)
 
 
 class QueryAndGroup(nn.Module):

@@ -1,5 +1,6 @@
-"""The stacked query-and-group backward WITHOUT float atomics (csrc/query_group.hip: qg_inv_count / qg_inv_fill /
-qg_stack_bwd_rows_kernel) and the BatchNorm backward that feeds it rows (csrc/bn_act.hip: bn_bwd_apply_t_kernel).
+"""The stacked query-and-group backward WITHOUT atomics (csrc/query_group.hip: qg_inv_index_kernel -- a stable counting sort
+in LDS --, qg_stack_bwd_rows_kernel, qg_stack_bwd_combine_kernel) and the BatchNorm backward that feeds it rows
+(csrc/bn_act.hip: bn_bwd_apply_t_kernel).
 
 Oracle: the scatter-add of the reference's group_points_grad_kernel_stack
 (pcdet/ops/pointnet2/pointnet2_stack/src/group_points_gpu.cu:15-46) restated in numpy float64 (np.add.at); the bar is
@@ -26,12 +27,26 @@ def _case(seed, counts_p, counts_q, nsample, C, empty_every=0):
     idx = np.zeros((M, nsample), np.int32)
     m0 = 0
     for npts, nq in zip(counts_p, counts_q):
-        idx[m0:m0 + nq] = rng.integers(0, npts, (nq, nsample))
+        if nq:
+            idx[m0:m0 + nq] = rng.integers(0, npts, (nq, nsample))
         m0 += nq
     if empty_every:
         idx[::empty_every, 0] = -1
     g = rng.standard_normal((C, M * nsample)).astype(np.float32)
-    return idx, g
+    xyz = rng.uniform(-20, 20, (int(sum(counts_p)), 3)).astype(np.float32)
+    new_xyz = rng.uniform(-20, 20, (M, 3)).astype(np.float32)
+    return idx, g, xyz, new_xyz
+
+
+def _oracle_wx(idx, g, xyz, new_xyz, counts_p, counts_q, nsample):
+    """d wx (C, 3) = sum over the live columns of g[:, col] (x) (xyz[src] - new_xyz[query]); the relative coordinates in fp32 as
+    the forward forms them (reference QueryAndGroup: grouped_xyz - new_xyz, pointnet2_stack/pointnet2_utils.py:150-151)."""
+    p_start = np.repeat(np.concatenate([[0], np.cumsum(counts_p)[:-1]]), counts_q)
+    live = idx[:, 0] >= 0
+    src = (p_start[:, None] + idx)
+    rel = (xyz[src] - new_xyz[:, None, :]).astype(np.float32)                  # (M, ns, 3)
+    rel[~live] = 0
+    return g.astype(np.float64) @ rel.reshape(-1, 3).astype(np.float64)
 
 
 def _oracle(idx, g, counts_p, counts_q, nsample):
@@ -47,30 +62,43 @@ def _oracle(idx, g, counts_p, counts_q, nsample):
 
 
 CASES = [  # (points per sample, queries per sample, nsample, C, ld, col, empty_every)
-    ((700, 650), (90, 81), 16, 32, 32, 0, 7),          # short lists (LDS sort path)
-    ((40, 3), (300, 200), 16, 24, 56, 24, 5),          # lists of ~100 and ~1000 entries: LDS path and the chunk-merge path
-    ((2,), (3000,), 32, 64, 64, 0, 0),                 # two rows with ~48 000 references each: many chunks per row
+    ((700, 650), (90, 81), 16, 32, 32, 0, 7),          # short lists: one work item per row
+    ((40, 3), (300, 200), 16, 24, 56, 24, 5),          # lists of ~100 and ~1000 entries: rows cut into several work items
+    ((2,), (3000,), 32, 64, 64, 0, 0),                 # two rows with ~48 000 references each: ~190 parts per row
     ((500,), (64,), 8, 7, 16, 3, 0),                   # odd channel count, strided destination
-    ((1,), (9000,), 32, 5, 5, 0, 0),                   # one row, 288 000 references: past the merge path (selection)
+    ((1,), (9000,), 32, 5, 5, 0, 0),                   # one row, 288 000 references
+    ((5000, 0, 2100), (400, 0, 333), 16, 32, 32, 0, 9),     # > 2048 rows per sample: several histogram passes; an empty sample
+    ((300, 200), (0, 150), 4, 16, 16, 0, 0),           # a sample without queries: its rows get no item
 ]
 
 
 @pytest.mark.parametrize("counts_p,counts_q,nsample,C,ld,col,empty_every", CASES)
 def test_rows_backward_matches_scatter_add_oracle_and_is_reproducible(counts_p, counts_q, nsample, C, ld, col, empty_every):
     from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as P
-    idx, g = _case(3, counts_p, counts_q, nsample, C, empty_every)
+    idx, g, xyz, new_xyz = _case(3, counts_p, counts_q, nsample, C, empty_every)
     want = _oracle(idx, g, counts_p, counts_q, nsample)
+    want_wx = _oracle_wx(idx, g, xyz, new_xyz, counts_p, counts_q, nsample)
     n, M = int(sum(counts_p)), int(sum(counts_q))
     d_idx = torch.from_numpy(idx).cuda()
     pc = torch.tensor(counts_p, dtype=torch.int32, device="cuda")
     qc = torch.tensor(counts_q, dtype=torch.int32, device="cuda")
     g_t = torch.from_numpy(np.ascontiguousarray(g.T)).cuda()                       # (M * nsample, C)
-    runs = []
+    d_xyz, d_new = torch.from_numpy(xyz).cuda(), torch.from_numpy(new_xyz).cuda()
+    runs, wxs = [], []
     for _ in range(3):
         out = torch.full((n, ld), 0.0, device="cuda")
-        P.query_group_proj_grad_rows_wrapper(len(counts_p), M, C, nsample, g_t, d_idx, qc, pc, out, zf_ld=ld, zf_col=col)
+        wx = P.query_group_proj_grad_rows_wrapper(len(counts_p), M, C, nsample, g_t, d_idx, qc, pc, out, zf_ld=ld, zf_col=col,
+                                                  xyz=d_xyz, new_xyz=d_new)
         runs.append(out.cpu().numpy())
+        wxs.append(wx.cpu().numpy())
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2]), "not bit-reproducible"
+    assert np.array_equal(wxs[0], wxs[1]) and np.array_equal(wxs[0], wxs[2]), "d wx not bit-reproducible"
+    assert wxs[0].shape == (C, 3) and np.abs(wxs[0] - want_wx).max() <= 2e-5 * np.abs(want_wx).max() + 1e-6, \
+        (np.abs(wxs[0] - want_wx).max(), np.abs(want_wx).max())
+    # without coordinates: the feature gradient alone, same bits
+    out = torch.zeros((n, ld), device="cuda")
+    assert P.query_group_proj_grad_rows_wrapper(len(counts_p), M, C, nsample, g_t, d_idx, qc, pc, out, zf_ld=ld, zf_col=col) is None
+    assert np.array_equal(out.cpu().numpy(), runs[0])
     got = runs[0][:, col:col + C]
     scale = np.abs(want).max()
     assert np.abs(got - want).max() <= 1e-5 * scale, (np.abs(got - want).max(), scale)
@@ -87,9 +115,10 @@ def test_rows_backward_empty_inputs():
     pc = torch.tensor([5], dtype=torch.int32, device="cuda")
     qc = torch.tensor([0], dtype=torch.int32, device="cuda")
     out = torch.zeros((5, 8), device="cuda")
-    P.query_group_proj_grad_rows_wrapper(1, 0, 8, 16, torch.zeros((0, 8), device="cuda"), torch.zeros((0, 16), dtype=torch.int32, device="cuda"),
-                                         qc, pc, out)
-    assert out.abs().sum().item() == 0
+    wx = P.query_group_proj_grad_rows_wrapper(1, 0, 8, 16, torch.zeros((0, 8), device="cuda"),
+                                              torch.zeros((0, 16), dtype=torch.int32, device="cuda"), qc, pc, out,
+                                              xyz=torch.zeros((5, 3), device="cuda"), new_xyz=torch.zeros((0, 3), device="cuda"))
+    assert out.abs().sum().item() == 0 and wx.shape == (8, 3) and wx.abs().sum().item() == 0
 
 
 @pytest.mark.parametrize("relu", [True, False])

@@ -29,7 +29,7 @@ KERNELS = {
     "rowmajor_dw_kernel": "mgar::rowmajor_dw_kernel", "maxpool3d_same_kernel": "mgar::maxpool3d_same",
     "fps_kernel": "mgar::fps_", "ball_query_kernel": "mgar::ball_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
     "three_interp_fwd": "mgar::three_interp_batch_fwd", "three_interp_bwd": "mgar::three_interp_batch_bwd",
-    "query_group_fwd": "mgar::qg_", "query_group_bwd": "mgar::qg_",
+    "query_group_fwd": "mgar::qg_", "query_group_bwd": "mgar::qg_", "query_group_inverse_index": "mgar::qg_inv_",
     "stem_conv3d_kernel": "mgar::stem_conv3d_kernel", "voxel_roi_pool_fwd": "mgar::vrp_fwd_kernel", "voxel_roi_pool_bwd": "mgar::vrp_bwd_kernel",
 }
 WIDE_READERS = {"bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel",
