@@ -179,25 +179,35 @@ __global__ __launch_bounds__(256) void pointwise_dw_kernel(const float *__restri
             }
 }
 
-// dw[e] = sum over the gx partials, in workgroup order.  256 threads = 64 outputs x 4 slices of gx.
-__global__ __launch_bounds__(256) void pointwise_dw_reduce_kernel(const float *__restrict__ partial, int gx, int n_out,
-                                                                  float *__restrict__ dw) {
-    __shared__ float part[4][64];
+// dw[e] = sum over the gx partials in a fixed order: 1024 threads = 64 outputs x 16 slices of gx, every slice summed in
+// workgroup order with 8 loads in flight, then the slices in order.  (Round 1 ran 4 slices of up to 512 dependent loads:
+// 52 us per launch, 19 launches per step, for a few KB of output.)
+constexpr int DWR_SLICES = 16;
+__global__ __launch_bounds__(64 * DWR_SLICES) void pointwise_dw_reduce_kernel(const float *__restrict__ partial, int gx, int n_out,
+                                                                              float *__restrict__ dw) {
+    __shared__ float part[DWR_SLICES][64];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    const int per = (gx + 3) / 4, g0 = slice * per, g1 = min(g0 + per, gx);
+    const int per = (gx + DWR_SLICES - 1) / DWR_SLICES, g0 = min(slice * per, gx), g1 = min(g0 + per, gx);
     float s = 0.f;
     if (e < n_out) {
         int g = g0;
-        for (; g + 4 <= g1; g += 4) {
-            const float a = partial[(size_t)g * n_out + e], b = partial[(size_t)(g + 1) * n_out + e];
-            const float c = partial[(size_t)(g + 2) * n_out + e], d = partial[(size_t)(g + 3) * n_out + e];
-            s = (((s + a) + b) + c) + d;
+        for (; g + 8 <= g1; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + u) * n_out + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
         }
         for (; g < g1; ++g) s += partial[(size_t)g * n_out + e];
     }
     part[slice][threadIdx.x & 63] = s;
     __syncthreads();
-    if (slice == 0 && e < n_out) dw[e] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (slice == 0 && e < n_out) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < DWR_SLICES; ++i) t += part[i][threadIdx.x];
+        dw[e] = t;
+    }
 }
 
 static int dw_grid_x(int B, int Cin, int Cout, int P, int ob, int ib) {
@@ -266,7 +276,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_pointwise_conv_dw_act
     else launch_dw<2, 4>(x, dy, B, Cin, Cout, P, act, workspace, st);
     }
     const int gx = dw_grid_x(B, Cin, Cout, P, ob, ib), n_out = Cout * Cin;
-    hipLaunchKernelGGL(pointwise_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(256), 0, st, workspace, gx, n_out, dw);
+    hipLaunchKernelGGL(pointwise_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(64 * DWR_SLICES), 0, st, workspace, gx, n_out, dw);
     return check_launch("pointwise_conv_dw: launch failed");
 }
 

@@ -87,18 +87,33 @@ __global__ __launch_bounds__(256) void rowmajor_dw_kernel(const float *__restric
             }
 }
 
-// same fixed-order reduce as csrc/pointwise_dw.hip: 256 threads = 64 outputs x 4 slices of the partials
-__global__ __launch_bounds__(256) void rowmajor_dw_reduce_kernel(const float *__restrict__ partial, int np, int n_out,
-                                                                 float *__restrict__ dw) {
-    __shared__ float part[4][64];
+// same fixed-order reduce as csrc/pointwise_dw.hip: 1024 threads = 64 outputs x 16 slices of the partials, 8 loads in flight
+constexpr int RDR_SLICES = 16;
+__global__ __launch_bounds__(64 * RDR_SLICES) void rowmajor_dw_reduce_kernel(const float *__restrict__ partial, int np, int n_out,
+                                                                             float *__restrict__ dw) {
+    __shared__ float part[RDR_SLICES][64];
     const int e = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
-    const int per = (np + 3) / 4, g0 = slice * per, g1 = min(g0 + per, np);
+    const int per = (np + RDR_SLICES - 1) / RDR_SLICES, g0 = min(slice * per, np), g1 = min(g0 + per, np);
     float s = 0.f;
-    if (e < n_out)
-        for (int g = g0; g < g1; ++g) s += partial[(size_t)g * n_out + e];
+    if (e < n_out) {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(g + u) * n_out + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; g < g1; ++g) s += partial[(size_t)g * n_out + e];
+    }
     part[slice][threadIdx.x & 63] = s;
     __syncthreads();
-    if (slice == 0 && e < n_out) dw[e] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (slice == 0 && e < n_out) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < RDR_SLICES; ++i) t += part[i][threadIdx.x];
+        dw[e] = t;
+    }
 }
 
 static int rd_workgroups(long long N) {
@@ -148,6 +163,6 @@ extern "C" __attribute__((visibility("default"))) int mgar_rowmajor_dw(const flo
     }
 #undef RD_CASE
     const int np = rd_workgroups(N) * 4, n_out = Co * Ci;
-    hipLaunchKernelGGL(rowmajor_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(256), 0, st, workspace, np, n_out, dw);
+    hipLaunchKernelGGL(rowmajor_dw_reduce_kernel, dim3(ceil_div(n_out, 64)), dim3(64 * RDR_SLICES), 0, st, workspace, np, n_out, dw);
     return check_launch("rowmajor_dw: launch failed");
 }

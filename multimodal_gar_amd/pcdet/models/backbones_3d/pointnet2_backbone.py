@@ -8,6 +8,45 @@ import torch.nn as nn
 from ...ops.pointnet2.pointnet2_batch import pointnet2_modules
 
 
+class TrunkGeometry:
+    """Results of PointNet2MSG.geometry() with the events that order them against the consumer's stream."""
+
+    def __init__(self):
+        self.centres, self.ball_idx, self.centre_events, self.idx_events = [], [], [], []
+        self.nn, self.nn_events = {}, {}
+
+    @staticmethod
+    def _mark():
+        return torch.cuda.current_stream().record_event() if torch.cuda.is_available() else None
+
+    @staticmethod
+    def _wait(ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def add_level(self, centres, idx):
+        self.centres.append(centres)
+        self.ball_idx.append(idx)
+        self.centre_events.append(self._mark())
+        self.idx_events.append(None)
+
+    def set_ball_idx(self, k, idx):
+        self.ball_idx[k] = idx
+        self.idx_events[k] = self._mark()
+
+    def add_neighbours(self, i, idx_weight):
+        self.nn[i] = idx_weight
+        self.nn_events[i] = self._mark()
+
+    def level(self, k):
+        self._wait(self.idx_events[k] if self.idx_events[k] is not None else self.centre_events[k])
+        return self.centres[k], self.ball_idx[k]
+
+    def neighbours(self, i):
+        self._wait(self.nn_events[i])
+        return self.nn[i]
+
+
 class PointNet2MSG(nn.Module):
     def __init__(self, model_cfg, input_channels, **kwargs):
         super().__init__()
@@ -32,6 +71,29 @@ class PointNet2MSG(nn.Module):
             self.FP_modules.append(pointnet2_modules.PointnetFPModule(mlp=[pre + skip_channels[k]] + list(fp[k])))
         self.num_point_features = fp[0][-1]
 
+    def geometry(self, points, stream=None, levels=None, balls=True, neighbours=True):
+        """Everything of the trunk that depends on coordinates only -- per SA level the FPS centres and the ball queries of
+        the folded scales, per FP level the 3-NN interpolation weights -- issued on ``stream`` (default: the current one)
+        ahead of the feature path.  points (B, n, >= 3).  -> TrunkGeometry for batch_dict['trunk_geometry']; same values as
+        the modules compute.  Everything, the slicing of ``points`` included, is issued on ``stream``.  ``levels`` / ``balls`` /
+        ``neighbours`` restrict it (first SA levels only / no ball queries / no 3-NN); the modules compute the rest inline."""
+        import contextlib
+        geo = TrunkGeometry()
+        with torch.no_grad(), (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
+            l_xyz = [points[..., :3].contiguous()]
+            n_feat = self.SA_modules[0].mlps[0][0].in_channels - 3
+            for sa in self.SA_modules[:levels]:
+                centres = sa.pick_centres(l_xyz[-1])
+                geo.add_level(centres, None)                     # the centres first: the feature path of level 1 waits for them
+                idx = sa.ball_indices(l_xyz[-1], centres, n_feat if n_feat > 0 else None) if balls else None
+                geo.set_ball_idx(len(l_xyz) - 1, idx)
+                l_xyz.append(centres)
+                n_feat = sum(m[-3].out_channels for m in sa.mlps)
+            for i in range(-1, -(len(self.FP_modules) + 1), -1):
+                if neighbours and levels is None:
+                    geo.add_neighbours(i, self.FP_modules[i].neighbour_weights(l_xyz[i - 1], l_xyz[i]))
+        return geo
+
     @staticmethod
     def break_up_pc(pc):
         return pc[:, 0], pc[:, 1:4].contiguous(), (pc[:, 4:].contiguous() if pc.size(-1) > 4 else None)
@@ -49,15 +111,21 @@ class PointNet2MSG(nn.Module):
                 # written in bf16 by the fused query-and-group kernel (coordinates stay fp32)
                 features = features.to(torch.get_autocast_dtype('cuda'))
         l_xyz, l_features = [xyz], [features]
-        # optional: centres picked ahead of time by the caller (same FPS, issued earlier so that it overlaps other
-        # work -- one workgroup per cloud leaves most of the chip idle); SA modules take new_xyz as in the reference
+        # optional: the trunk's GEOMETRY (centres, ball queries, 3-NN weights depend on coordinates only) computed ahead of
+        # time by the caller on another stream -- same values; SA / FP modules take them as the reference takes new_xyz
+        geo = batch_dict.get('trunk_geometry')
         pre = batch_dict.get('sa_new_xyz') or []
         for k, sa in enumerate(self.SA_modules):
-            li_xyz, li_features = sa(l_xyz[-1], l_features[-1], new_xyz=pre[k] if k < len(pre) else None)
+            if geo is not None and k < len(geo.centres):
+                centres, ball_idx = geo.level(k)
+                li_xyz, li_features = sa(l_xyz[-1], l_features[-1], new_xyz=centres, pre_idx=ball_idx)
+            else:
+                li_xyz, li_features = sa(l_xyz[-1], l_features[-1], new_xyz=pre[k] if k < len(pre) else None)
             l_xyz.append(li_xyz)
             l_features.append(li_features)
         for i in range(-1, -(len(self.FP_modules) + 1), -1):
-            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i])
+            l_features[i - 1] = self.FP_modules[i](l_xyz[i - 1], l_xyz[i], l_features[i - 1], l_features[i],
+                                                   nn_weights=geo.neighbours(i) if geo is not None and i in geo.nn else None)
         # (B, C, n) channel-major, as produced: consumers on the device take this (no transposed copy of ~1 GB)
         batch_dict['point_features_cm'] = l_features[0]
         if self.model_cfg.get('STACKED_POINT_FEATURES', True) or not xyz.is_cuda:   # the reference's key (pointnet2_backbone.py:91-92)

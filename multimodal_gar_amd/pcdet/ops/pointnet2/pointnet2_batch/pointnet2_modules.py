@@ -39,23 +39,40 @@ class _PointnetSAModuleBase(nn.Module):
         self.mlps = None
         self.pool_method = 'max_pool'
 
+    def pick_centres(self, xyz):
+        """Farthest point sampling + gather: the centres of this level (reference pointnet2_modules.py:33-41)."""
+        picked = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
+        xyz_t = xyz.transpose(1, 2).contiguous()
+        return pointnet2_utils.gather_operation(xyz_t, picked).transpose(1, 2).contiguous()
+
+    def _fold_scales(self, n_feat, on_device):
+        """Scales whose first layer is applied to the points before the grouping ("project, then group"): device only."""
+        if not (self.pool_method == 'max_pool' and n_feat is not None and on_device):
+            return []
+        return [k for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps))
+                if isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz and mlp.first_layer_foldable(3 + n_feat)]
+
+    def ball_indices(self, xyz, new_xyz, n_feat):
+        """The ball queries of the folded scales in ONE scan of the cloud (they share centres and cloud) -> {scale: idx}.
+        Pure geometry: callable ahead of the features (model/../workload.py issues it on a side stream)."""
+        fold = self._fold_scales(n_feat, xyz.is_cuda)
+        if len(fold) > 1 and hasattr(pointnet2_utils.pointnet2, "ball_query_multi_wrapper"):
+            return dict(zip(fold, pointnet2_utils.ball_query_multi([self.groupers[k].radius for k in fold],
+                                                                   [self.groupers[k].nsample for k in fold], xyz, new_xyz)))
+        return {}
+
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
-                new_xyz=None) -> Tuple[torch.Tensor, torch.Tensor]:
+                new_xyz=None, pre_idx=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """xyz (B, N, 3), features (B, C, N) -> new_xyz (B, npoint, 3), (B, sum_k mlps[k][-1], npoint).
-        Reference: pointnet2_modules.py:19-55."""
+        Reference: pointnet2_modules.py:19-55.  ``new_xyz`` / ``pre_idx``: this level's centres / ball_indices() computed
+        ahead of time by the caller (same values)."""
         if new_xyz is None and self.npoint is not None:
-            picked = pointnet2_utils.farthest_point_sample(xyz, self.npoint)
-            xyz_t = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_t, picked).transpose(1, 2).contiguous()
+            new_xyz = self.pick_centres(xyz)
         per_scale = []
-        fold = [k for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps))
-                if (self.pool_method == 'max_pool' and features is not None and xyz.is_cuda
-                    and isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz
-                    and mlp.first_layer_foldable(3 + features.shape[1]))]
-        # the scales share centres and cloud: all their ball queries in one scan
-        pre_idx = dict(zip(fold, pointnet2_utils.ball_query_multi([self.groupers[k].radius for k in fold],
-                                                                  [self.groupers[k].nsample for k in fold], xyz, new_xyz))) \
-            if len(fold) > 1 and hasattr(pointnet2_utils.pointnet2, "ball_query_multi_wrapper") else {}
+        n_feat = None if features is None else features.shape[1]
+        fold = self._fold_scales(n_feat, xyz.is_cuda)
+        if pre_idx is None:
+            pre_idx = self.ball_indices(xyz, new_xyz, n_feat)
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if k in fold:
                 # "project, then group": layer 0 is linear, apply its feature half to the N points first
@@ -107,12 +124,18 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = shared_mlp_2d(mlp)
 
+    @staticmethod
+    def neighbour_weights(unknown, known):
+        """three_nn + inverse-distance weights (reference pointnet2_modules.py:137-140) -> (idx, weight): pure geometry."""
+        dist, idx = pointnet2_utils.three_nn(unknown, known)
+        inv = 1.0 / (dist + 1e-8)
+        return idx, inv / torch.sum(inv, dim=2, keepdim=True)
+
     def forward(self, unknown: torch.Tensor, known: torch.Tensor, unknow_feats: torch.Tensor,
-                known_feats: torch.Tensor) -> torch.Tensor:
+                known_feats: torch.Tensor, nn_weights=None) -> torch.Tensor:
+        """``nn_weights``: neighbour_weights(unknown, known) computed ahead of time by the caller (same values)."""
         if known is not None:
-            dist, idx = pointnet2_utils.three_nn(unknown, known)
-            inv = 1.0 / (dist + 1e-8)
-            weight = inv / torch.sum(inv, dim=2, keepdim=True)
+            idx, weight = nn_weights if nn_weights is not None else self.neighbour_weights(unknown, known)
             spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

@@ -129,7 +129,12 @@ class ClipModel(nn.Module):
         self.net.GAR_model.uniform_actor_count = n_actors
         self.overlap_branches = True
         self.batch_i3d = True
-        self._side_stream = None
+        self._side_stream = self._geo_stream = None
+        # What of the trunk's coordinate-only work is issued ahead of the feature path: "fps1" = the level-1 FPS, on the main
+        # stream before the I3D launches (round 1); "all" = every level's FPS, ball queries and 3-NN weights on a third
+        # stream.  "all" measured SLOWER inside the HIP graph (1 clip: 45.4 vs 42.3 ms; c3: 244.2 vs 235.2 ms/step,
+        # profiles/README.md round 2): the extra branch delays the feature path's kernels more than it hides.
+        self.geometry_ahead = "fps1"
 
     # ---- RGB: one I3D pass per clip (batch 1, like the reference) ---------------------------------
     def rgb_crops(self, images, bboxes):
@@ -173,19 +178,18 @@ class ClipModel(nn.Module):
         return self.rgb_tokens_from_crops(self.rgb_crops(images, bboxes))
 
     # ---- LiDAR: all frames of all clips in one batch ------------------------------------------------
-    def first_level_centres(self, points):
-        """Level-1 farthest point sampling of the PointNet++ trunk, callable ahead of the trunk: FPS runs one
-        workgroup per cloud for ~7 ms (6-47 % of the CUs), so it is issued first and overlaps the I3D work."""
+    def trunk_geometry(self, points, stream=None):
+        """The coordinate-only part of the PointNet++ trunk (FPS centres of the four levels, ball queries of the folded
+        scales, 3-NN weights of the decoder), issued ahead of the feature path on ``stream``: level-1 FPS runs one workgroup
+        per cloud for ~5 ms (6-47 % of the CUs) and overlaps the I3D work (see ``geometry_ahead``)."""
         if self.route != "pointnet2":
             return None
-        from .pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pb
-        sa0 = self.net.LiDAR_backbone.model.backbone_3d.SA_modules[0]
-        with torch.no_grad():
-            xyz = points[..., :3].contiguous()
-            picked = pb.farthest_point_sample(xyz, sa0.npoint)
-            return pb.gather_operation(xyz.transpose(1, 2).contiguous(), picked).transpose(1, 2).contiguous()
+        trunk = self.net.LiDAR_backbone.model.backbone_3d
+        if self.geometry_ahead == "all":
+            return trunk.geometry(points, stream)
+        return trunk.geometry(points, stream, levels=1, balls=False, neighbours=False)
 
-    def lidar_tokens(self, points, bboxes3d, new_xyz1=None):
+    def lidar_tokens(self, points, bboxes3d, geometry=None):
         f, p, _ = points.shape
         a = self.n_actors
         lb = self.net.LiDAR_backbone
@@ -194,8 +198,8 @@ class ClipModel(nn.Module):
             data = {"batch_size": f, "points": torch.cat([bidx, points], -1).view(f * p, 5),
                     "gt_boxes": bboxes3d[:, :a, :].contiguous(),
                     "point_batch_cnt": torch.full((f,), p, dtype=torch.int32, device=points.device)}
-            if new_xyz1 is not None:
-                data["sa_new_xyz"] = [new_xyz1]
+            if geometry is not None:
+                data["trunk_geometry"] = geometry
         else:
             data = voxelize_batch(points, self.dataset)
             data["gt_boxes"] = bboxes3d[:, :a, :].contiguous()
@@ -211,14 +215,16 @@ class ClipModel(nn.Module):
             # replay lives on the side stream, so gradient hooks (DDP) only ever see the main stream.
             main = torch.cuda.current_stream()
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
+                self._side_stream, self._geo_stream = torch.cuda.Stream(), torch.cuda.Stream()
             inputs_ready = main.record_event()
-            new_xyz1 = self.first_level_centres(batch["points"])
+            self._geo_stream.wait_event(inputs_ready)
+            geometry = self.trunk_geometry(batch["points"], self._geo_stream if self.geometry_ahead == "all" else main)   # FPS first
             self._side_stream.wait_event(inputs_ready)
             with torch.cuda.stream(self._side_stream):
                 crops = self.rgb_crops(batch["images"], batch["bboxes"])
-            lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], new_xyz1)   # (B*T, A, 512)
+            lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], geometry)   # (B*T, A, 512)
             main.wait_stream(self._side_stream)
+            main.wait_stream(self._geo_stream)
             if not torch.cuda.is_current_stream_capturing():   # inside a graph the pool is private and replays are serial
                 for c in crops:
                     c.record_stream(main)

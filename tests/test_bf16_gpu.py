@@ -346,6 +346,9 @@ def test_forward_bf16_at_full_c2_size_vs_fp32_device_path():
     batch = W.make_batch(32, 4, 15, 16, 8192, 224, 384, torch.device("cuda"))
     logs, outs = {}, {}
     for prec in ("fp32", "bf16"):
+        # one throw-away pass first: on its first call for a shape the convolution library times its candidate kernels and
+        # the result of that call is not guaranteed to come from the kernel it settles on (the graph below replays that one)
+        steps[prec].run_eager(batch)
         with _IndexRecorder() as rec:
             outs[prec] = steps[prec].run_eager(batch)
         torch.cuda.synchronize()

@@ -161,6 +161,15 @@ def test_clip_model_train_mode_several_clips_gpu_vs_cpu_backend():
     assert len(got) == 16
     for a, b in zip(got, want):
         close(a, b, rtol=2e-3, atol=1e-5)      # train-mode BatchNorm over few samples amplifies fp32 rounding
+    # the whole coordinate-only part of the trunk (every level's FPS, ball queries, 3-NN weights) issued ahead on a third
+    # stream: the same numbers, bit for bit (pcdet/models/backbones_3d/pointnet2_backbone.py: PointNet2MSG.geometry)
+    assert gm.geometry_ahead == "fps1"
+    gm.geometry_ahead = "all"
+    with torch.no_grad():
+        ahead = gm(gb)
+    torch.cuda.synchronize()
+    for a, b in zip(ahead, got):
+        assert torch.equal(a, b)
 
 
 def _reference_style_batch(seed, n_actors, n_points, route, ds):
