@@ -127,6 +127,15 @@ int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *g
  * summation order. */
 int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m, const float *grad_out, const int *list,
                                              float *grad_points, void *stream);
+/* Both with grad_out a CHANNEL SLICE of a wider (b, c_total, n) tensor: consecutive samples are grad_out_bstride >= c * n
+ * elements apart.  The decoder (reference PointnetFPModule, pointnet2_batch/pointnet2_modules.py:139-148) concatenates the
+ * interpolated features with the skip features; the gradient of that torch.cat hands this op a slice, which the reference's
+ * wrapper first copies (grad_out.contiguous()): up to 2 GB per launch at config c3. */
+int mgar_three_interpolate_grad_batch_strided(int b, int c, int n, int m, const float *grad_out, long long grad_out_bstride,
+                                              const int *idx, const float *weight, float *grad_points, void *stream);
+int mgar_three_interpolate_grad_sorted_batch_strided(int b, int c, int n, int m, const float *grad_out,
+                                                     long long grad_out_bstride, const int *list, float *grad_points,
+                                                     void *stream);
 
 /* ============== pointnet2_stack: (N1+N2+..., 3|C) + per-sample counts ================= */
 
@@ -301,12 +310,24 @@ int mgar_bn_act_fwd_grouped(const float *x, int G, int C, int P, const float *me
                             const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *y, void *stream);
+/* bn_act_fwd (stats_per_sample = 0) / bn_act_fwd_grouped (1) with y a CHANNEL SLICE of a wider (B, C_total, P) tensor:
+ * consecutive samples of y are y_bstride >= C * P elements apart.  The branches of an Inception module (reference
+ * model/backbone.py:227-260: torch.cat of four branch outputs) write straight into the concatenated tensor. */
+int mgar_bn_act_fwd_into(const float *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
+                         const float *beta, int relu, int stats_per_sample, float *y, long long y_bstride, void *stream);
 int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, const float *mean,
                             const float *invstd, const float *gamma, const float *beta, int relu, float *out,
                             unsigned char *arg, float *xarg, void *stream);
 int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
                     float *dbeta, float *dx, void *stream);
+/* mgar_bn_act_maxpool_bwd with dpool read IN PLACE from a strided tensor: element (b, c, m) at dpool[b*sb + c*sc + m*sm]
+ * -- a channel slice of a wider (B, C_total, M) tensor (gradient of the torch.cat over the scales of an SA module,
+ * reference pointnet2_modules.py:55) or the transposed view of (M, C_total) rows -- instead of a copy first. */
+int mgar_bn_act_maxpool_bwd_strided(const float *dpool, long long sb, long long sc, long long sm, const float *pooled,
+                                    const unsigned char *arg, const float *x, const float *xarg, int B, int C, int M,
+                                    int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
+                                    float *workspace, float *dgamma, float *dbeta, float *dx, void *stream);
 /* mgar_bn_act_bwd with the input gradient written ROW-MAJOR, dx_t (B*P, C), C <= 64: the layout the atomic-free stack
  * grouping backward (mgar_query_group_stack_bwd_rows) gathers from. */
 int mgar_bn_act_bwd_rowmajor(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
@@ -521,6 +542,8 @@ int mgar_bn_train_stats_grouped_bf16(const void *x, int G, int C, int P, float e
 /* x, y */
 int mgar_bn_act_fwd_bf16(const void *x, int B, int C, int P, const float *mean, const float *invstd,
                          const float *gamma, const float *beta, int relu, void *y, void *stream);
+int mgar_bn_act_fwd_into_bf16(const void *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
+                              const float *beta, int relu, int stats_per_sample, void *y, long long y_bstride, void *stream);
 int mgar_bn_act_fwd_grouped_bf16(const void *x, int G, int C, int P, const float *mean, const float *invstd,
                                  const float *gamma, const float *beta, int relu, void *y, void *stream);
 /* x, out, xarg */

@@ -37,6 +37,8 @@ _PROTOS = {
     "mgar_three_interpolate_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_sorted_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_three_interpolate_grad_batch_strided": [_I, _I, _I, _I, _P, _LL, _P, _P, _P, _P],
+    "mgar_three_interpolate_grad_sorted_batch_strided": [_I, _I, _I, _I, _P, _LL, _P, _P, _P],
     "mgar_ball_query_stack": [_I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_query_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_query_hash_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -67,6 +69,8 @@ _PROTOS = {
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_act_maxpool_bwd_strided": [_P, _LL, _LL, _LL, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_act_fwd_into": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _LL, _P],
     "mgar_bn_act_bwd_rowmajor": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_query_group_stack_inverse_items": [_I, _I, _LL],
     "mgar_query_group_stack_inverse_workspace_ints": [_I, _I, _LL],
@@ -104,7 +108,7 @@ _PROTOS = {
 # bf16-payload twins (include/mgar_ops.h, last section): identical argument lists
 for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_query_group_proj_batch_fwd",
            "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
-           "mgar_bn_act_fwd_grouped", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
+           "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
            "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_stack",
            "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]

@@ -115,7 +115,15 @@ class _BnActMaxPool(Function):
         dx = torch.empty_like(x4)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dt = x4.dtype
-        dpool_c, ws = dpool.contiguous().to(dt), _workspace(x4, b, c, m * ns)
+        ws = _workspace(x4, b, c, m * ns)
+        if dt == torch.float32 and dpool.dtype == dt and dpool.dim() == 3 and not dpool.is_contiguous() \
+                and (b == 1 or dpool.stride(0) >= 0) and min(dpool.stride(1), dpool.stride(2)) >= 1:
+            # a channel slice of the concatenated scales, or the transposed view of (M, C_total) rows: read in place
+            L.call("mgar_bn_act_maxpool_bwd_strided", dpool.data_ptr(), dpool.stride(0) if b > 1 else 0, dpool.stride(1), dpool.stride(2),
+                   L.fptr(out), _u8ptr(arg), L.fptr(x4), L.fptr(xarg) if xarg is not None else None, b, c, m, ns, L.fptr(mean),
+                   L.fptr(invstd), L.fptr(gamma), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), L.stream_of(x4))
+            return dx, dgamma, dbeta, None, None, None
+        dpool_c = dpool.contiguous().to(dt)
         L.payload_call("mgar_bn_act_maxpool_bwd", dt, L.pptr(dpool_c, dt), L.pptr(out, dt), _u8ptr(arg), L.pptr(x4, dt),
                        L.pptr(xarg, dt) if xarg is not None else None, b, c, m, ns, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
                        int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.pptr(dx, dt), L.stream_of(x4))
@@ -204,17 +212,43 @@ def _stats(x3, bn):
     return _f32(bn.running_mean), torch.rsqrt(_f32(bn.running_var) + bn.eps)
 
 
-def bn_act(x, bn, relu, rowmajor_grad=False):
-    """[relu](bn(x)) for x (B, C, ...) contiguous on the device; ``bn`` is the nn.BatchNormNd module."""
+def _slice_stride(out, x):
+    """out: a (B, C, ...) CHANNEL SLICE of a wider contiguous (B, C_total, ...) tensor (what y[:, c0:c1] is) with x's shape
+    and dtype -> its batch stride in elements, or None if it is anything else."""
+    if out is None or out.shape != x.shape or out.dtype != x.dtype or not out.is_cuda:
+        return None
+    inner = 1
+    for size, stride in zip(reversed(out.shape[1:]), reversed(out.stride()[1:])):
+        if size != 1 and stride != inner:
+            return None
+        inner *= size
+    return out.stride(0) if out.stride(0) >= inner else None
+
+
+def _apply_into(x3, bn, relu, mean, invstd, per_sample, out, bstride):
+    b, c, p = x3.shape
+    gamma, beta = _affine(bn, c, x3.device)
+    dt = x3.dtype
+    L.payload_call("mgar_bn_act_fwd_into", dt, L.pptr(x3, dt), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+                   int(relu), int(per_sample), out.data_ptr(), bstride, L.stream_of(x3))
+    return out
+
+
+def bn_act(x, bn, relu, rowmajor_grad=False, out=None):
+    """[relu](bn(x)) for x (B, C, ...) contiguous on the device; ``bn`` is the nn.BatchNormNd module.
+    ``out``: write the result into this channel slice of a wider tensor (forward-only callers; see _slice_stride)."""
     x3 = x.contiguous().flatten(2) if x.dim() > 2 else x.contiguous().unsqueeze(-1)
     if not bn.training and torch.is_grad_enabled() and x.requires_grad:
         return None  # eval-mode backward: let the caller take the plain torch path
     mean, invstd = _stats(x3, bn)
+    bstride = _slice_stride(out, x)
+    if bstride is not None and x.dtype in _PAYLOADS and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
+        return _apply_into(x3, bn, relu, mean, invstd, False, out, bstride)
     gamma, beta = _affine(bn, x3.shape[1], x.device)
     return _BnAct.apply(x3, gamma, beta, mean, invstd, relu, rowmajor_grad).view(x.shape)
 
 
-def bn_act_per_sample(x, bn, relu):
+def bn_act_per_sample(x, bn, relu, out=None):
     """[relu](bn(x)) where every sample of x (G, C, ...) is normalised with its own batch statistics and the running
     statistics get the G momentum updates in sample order: G clips through a train-mode BatchNorm in ONE pass, with
     the result of feeding them one at a time.  Forward only (frozen I3D); None if that does not apply."""
@@ -236,6 +270,9 @@ def bn_act_per_sample(x, bn, relu):
                    L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
                    L.fptr(bn.running_var) if track else None,
                    L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None, st)
+    bstride = _slice_stride(out, x)
+    if bstride is not None:
+        return _apply_into(x3, bn, relu, mean, invstd, True, out, bstride)
     gamma, beta = _affine(bn, c, x.device)
     y = torch.empty_like(x3)
     L.payload_call("mgar_bn_act_fwd_grouped", dt, L.pptr(x3, dt), g, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),

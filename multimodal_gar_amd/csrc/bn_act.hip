@@ -133,7 +133,7 @@ template <bool RELU, typename T>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restrict__ x, int C, int P,
                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
                                                               const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                              T *__restrict__ y, int stats_per_row) {
+                                                              T *__restrict__ y, int stats_per_row, long long y_bstride) {
     const int row = blockIdx.x;
     const int c = row % C;
     const int sidx = stats_per_row ? row : c;   // per-sample statistics: mean / invstd have one entry per (sample, channel)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const T *__restric
     const float sc = invstd[sidx] * (gamma ? gamma[c] : 1.f);
     const float mu = mean[sidx], sh = beta ? beta[c] : 0.f;
     const T *xr = x + (size_t)row * P;
-    T *yr = y + (size_t)row * P;
+    T *yr = y + (size_t)(row / C) * y_bstride + (size_t)c * P;   // y_bstride = C * P, or more: y is a channel slice of a wider tensor
     const int base = blockIdx.y * (BN_THREADS * 4 * BN_APPLY_V);
     if ((P & 3) == 0) {
 #pragma unroll
@@ -297,6 +297,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T *__r
     }
 }
 
+// where element (b, c, m) of the pooled gradient lives: contiguous (C*M, M, 1); a channel slice of a wider (B, C_total, M) tensor
+// (C_total*M, M, 1); or a transposed view of (M, C_total) rows (-, 1, C_total) -- read in place instead of copied first
+struct DpoolStrides {
+    long long b, c, m;
+};
+
 // after a fused max-pool only the arg-max element of every group carries gradient:
 // 13 B read per GROUP.  grid (nchunk over B*M, C)
 template <bool RELU, typename T>
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const T 
                                                                         const T *__restrict__ xarg, int B, int C, int M, int NS,
                                                                         const float *__restrict__ mean,
                                                                         const float *__restrict__ invstd,
-                                                                        float *__restrict__ partial) {
+                                                                        float *__restrict__ partial, DpoolStrides ds) {
     __shared__ float scratch[BN_THREADS / 64];
     const int c = blockIdx.y;
     const float mu = mean[c], is = invstd[c];
@@ -317,7 +323,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const T 
     float s = 0.f, q = 0.f;
     for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
         const size_t o = chan_off(e, c, C, M);
-        float d = Payload<T>::ld(dpool + o);
+        const long long eb = e / M;
+        float d = Payload<T>::ld(dpool + eb * ds.b + c * ds.c + (e - eb * M) * ds.m);
         if (RELU && !(Payload<T>::ld(pooled + o) > 0.f)) d = 0.f;
         const float xh = ((xarg ? Payload<T>::ld(xarg + o) : Payload<T>::ld(x + o * NS + arg[o])) - mu) * is;
         s += d;
@@ -424,7 +431,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const T *_
                                                                       const float *__restrict__ mean,
                                                                       const float *__restrict__ invstd,
                                                                       const float *__restrict__ gamma,
-                                                                      const float *__restrict__ coef, T *__restrict__ dx) {
+                                                                      const float *__restrict__ coef, T *__restrict__ dx,
+                                                                      DpoolStrides ds) {
     const int row = blockIdx.x;
     const int c = row % C;
     const float mu = mean[c], is = invstd[c];
@@ -437,7 +445,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_apply_kernel(const T *_
     const long long p0 = ((long long)blockIdx.y * BN_THREADS + threadIdx.x) * step;
     if (p0 >= P) return;
     const int m = (int)(p0 / NS), s0 = (int)(p0 - (long long)m * NS);
-    float d = Payload<T>::ld(dpool + go + m);
+    float d = Payload<T>::ld(dpool + (long long)(row / C) * ds.b + c * ds.c + m * ds.m);
     if (RELU && !(Payload<T>::ld(pooled + go + m) > 0.f)) d = 0.f;
     const int a = arg[go + m];
     if (step == 4) {
@@ -503,16 +511,20 @@ static int bn_train_stats_impl(const T *x, int B, int C, int P, float eps, float
 
 template <typename T>
 static int bn_act_fwd_impl(const T *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
-                           const float *beta, int relu, T *y, int stats_per_row, void *stream) {
+                           const float *beta, int relu, T *y, int stats_per_row, void *stream, long long y_bstride = -1) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_fwd: bad sizes");
+    if (y_bstride < 0) y_bstride = (long long)C * P;
+    MGAR_REQUIRE(y_bstride >= (long long)C * P, "bn_act_fwd: output batch stride smaller than a sample");
+    MGAR_REQUIRE((P & 3) != 0 || ((y_bstride * (long long)sizeof(T)) % 16 == 0 && (uintptr_t)y % 16 == 0),
+                 "bn_act_fwd: output slice not 16-byte aligned");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(x && y && mean && invstd, "bn_act_fwd: null pointer");
     MGAR_REQUIRE((long long)P <= 65535LL * BN_THREADS * 4, "bn_act_fwd: P too large");
     dim3 grid(B * C, ceil_div(P, BN_THREADS * 4 * BN_APPLY_V));
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_APPLY, st, 2.0 * sizeof(T) * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, stats_per_row);
-    else hipLaunchKernelGGL((bn_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, stats_per_row);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, stats_per_row, y_bstride);
+    else hipLaunchKernelGGL((bn_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, x, C, P, mean, invstd, gamma, beta, y, stats_per_row, y_bstride);
     }
     return check_launch("bn_act_fwd: launch failed");
 }
@@ -618,8 +630,10 @@ template <typename T>
 static int bn_act_maxpool_bwd_impl(const T *dpool, const T *pooled, const unsigned char *arg, const T *x,
                                    const T *xarg, int B, int C, int M, int nsample, const float *mean, const float *invstd,
                                    const float *gamma, int relu, float *workspace, float *dgamma, float *dbeta, T *dx,
-                                   void *stream) {
+                                   void *stream, long long dp_bs = -1, long long dp_cs = -1, long long dp_ms = 1) {
     MGAR_REQUIRE(bn_sizes_ok(B, C, (long long)M * nsample) && nsample >= 1 && nsample <= 255, "bn_act_maxpool_bwd: bad sizes");
+    const DpoolStrides ds{dp_bs < 0 ? (long long)C * M : dp_bs, dp_cs < 0 ? (long long)M : dp_cs, dp_ms};
+    MGAR_REQUIRE(ds.b >= 0 && ds.c >= 1 && ds.m >= 1, "bn_act_maxpool_bwd: bad dpool strides");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(dpool && pooled && arg && x && mean && invstd && workspace && dx, "bn_act_maxpool_bwd: null pointer");
     MGAR_REQUIRE(C <= 65535 && (long long)M * nsample <= 65535LL * BN_THREADS, "bn_act_maxpool_bwd: C > 65535 or M*nsample too large");
@@ -627,15 +641,15 @@ static int bn_act_maxpool_bwd_impl(const T *dpool, const T *pooled, const unsign
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_MAX_BWD_REDUCE, st, (3.0 * sizeof(T) + 1.0) * (double)B * C * M);
-    if (relu) hipLaunchKernelGGL((bn_max_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
-    else hipLaunchKernelGGL((bn_max_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace);
+    if (relu) hipLaunchKernelGGL((bn_max_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace, ds);
+    else hipLaunchKernelGGL((bn_max_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace, ds);
     }
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div((long long)M * nsample, BN_THREADS * ((nsample & 3) == 0 ? 4 : 1)));
     { KtScope kt(KT_BN_MAX_BWD_APPLY, st, (double)B * C * M * (2.0 * sizeof(T) * nsample + 2.0 * sizeof(T) + 1.0));
-    if (relu) hipLaunchKernelGGL((bn_max_bwd_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
-    else hipLaunchKernelGGL((bn_max_bwd_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx);
+    if (relu) hipLaunchKernelGGL((bn_max_bwd_apply_kernel<true, T>), grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx, ds);
+    else hipLaunchKernelGGL((bn_max_bwd_apply_kernel<false, T>), grid, dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, C, M, nsample, mean, invstd, gamma, coef, dx, ds);
     }
     return check_launch("bn_act_maxpool_bwd: launch failed");
 }
@@ -676,6 +690,15 @@ BN_BOTH(mgar_bn_act_fwd_grouped,
          int relu, void *y, void *stream),
         bn_act_fwd_impl<float>(x, G, C, P, mean, invstd, gamma, beta, relu, y, 1, stream),
         bn_act_fwd_impl<bf16_t>((cbf)x, G, C, P, mean, invstd, gamma, beta, relu, (mbf)y, 1, stream))
+// the same with y a CHANNEL SLICE of a wider (B, C_total, P) tensor: sample b of the result starts y_bstride elements after
+// sample b - 1 (an Inception module's branches write straight into the concatenated output: no torch.cat pass)
+BN_BOTH(mgar_bn_act_fwd_into,
+        (const float *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma, const float *beta,
+         int relu, int stats_per_sample, float *y, long long y_bstride, void *stream),
+        (const void *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma, const float *beta,
+         int relu, int stats_per_sample, void *y, long long y_bstride, void *stream),
+        bn_act_fwd_impl<float>(x, B, C, P, mean, invstd, gamma, beta, relu, y, stats_per_sample != 0, stream, y_bstride),
+        bn_act_fwd_impl<bf16_t>((cbf)x, B, C, P, mean, invstd, gamma, beta, relu, (mbf)y, stats_per_sample != 0, stream, y_bstride))
 BN_BOTH(mgar_bn_act_maxpool_fwd,
         (const float *x, int B, int C, int M, int nsample, const float *mean, const float *invstd, const float *gamma,
          const float *beta, int relu, float *out, unsigned char *arg, float *xarg, void *stream),
@@ -726,4 +749,17 @@ BN_API int mgar_bn_act_bwd_rowmajor(const float *dy, const float *x, int B, int 
     else hipLaunchKernelGGL(bn_bwd_apply_t_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx_t);
     }
     return check_launch("bn_act_bwd_rowmajor: launch failed");
+}
+
+// bn_act_maxpool_bwd with dpool read IN PLACE from a strided tensor: element (b, c, m) at dpool[b * sb + c * sc + m * sm].
+// Covers the two layouts the pooled gradient arrives in: a channel slice of a wider (B, C_total, M) tensor (the gradient
+// of the torch.cat over the scales of an SA module) and the transposed view of (M, C_total) rows (the RoI-grid lift's
+// consumer works on rows).  fp32.
+BN_API int mgar_bn_act_maxpool_bwd_strided(const float *dpool, long long sb, long long sc, long long sm, const float *pooled,
+                                           const unsigned char *arg, const float *x, const float *xarg, int B, int C, int M,
+                                           int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
+                                           float *workspace, float *dgamma, float *dbeta, float *dx, void *stream) {
+    MGAR_REQUIRE(sb >= 0 && sc >= 1 && sm >= 1, "bn_act_maxpool_bwd_strided: bad strides");
+    return bn_act_maxpool_bwd_impl<float>(dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, gamma, relu, workspace, dgamma,
+                                          dbeta, dx, stream, sb, sc, sm);
 }

@@ -165,7 +165,7 @@ __device__ __forceinline__ void seg_scan_step(int key, float (&v)[CH], bool has_
 
 template <int CH>
 __global__ __launch_bounds__(1024) void three_interp_batch_bwd_sorted_kernel(int c, int n, int m,
-                                                                             const float *__restrict__ grad_out,
+                                                                             const float *__restrict__ grad_out, size_t go_bs,
                                                                              const int2 *__restrict__ list,
                                                                              float *__restrict__ grad_points) {
     extern __shared__ float rows[];  // [CH][n]
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(1024) void three_interp_batch_bwd_sorted_kernel(int
     __shared__ float rec_sum[32][CH];
     const int c0 = blockIdx.x * CH, bs = blockIdx.y;
     const int nch = min(CH, c - c0);
-    const float *src = grad_out + ((size_t)bs * c + c0) * n;
+    const float *src = grad_out + (size_t)bs * go_bs + (size_t)c0 * n;
     if ((n & 3) == 0) {
         for (int i = threadIdx.x * 4; i < nch * n; i += blockDim.x * 4)
             *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int 
 // (n = 16384, c = 256, 120 clouds) the per-channel version re-read 12 GB of idx/weight from L2.
 // grid (ceil(c / CH), b)
 __global__ __launch_bounds__(1024) void three_interp_batch_bwd_lds_kernel(int c, int n, int m, int CH,
-                                                                          const float *__restrict__ grad_out,
+                                                                          const float *__restrict__ grad_out, size_t go_bs,
                                                                           const int *__restrict__ idx,
                                                                           const float *__restrict__ weight,
                                                                           float *__restrict__ grad_points) {
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(1024) void three_interp_batch_bwd_lds_kernel(int c,
     const int nch = min(CH, c - c0);
     for (int i = threadIdx.x; i < nch * m; i += blockDim.x) rows[i] = 0.f;
     __syncthreads();
-    const float *g = grad_out + ((size_t)bs * c + c0) * n;
+    const float *g = grad_out + (size_t)bs * go_bs + (size_t)c0 * n;
     for (int pt = threadIdx.x; pt < n; pt += blockDim.x) {
         const size_t o = ((size_t)bs * n + pt) * 3;
         const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(1024) void three_interp_batch_bwd_lds_kernel(int c,
 }
 
 __global__ __launch_bounds__(256) void three_interp_batch_bwd_atomic_kernel(int c, int n, int m,
-                                                                            const float *__restrict__ grad_out,
+                                                                            const float *__restrict__ grad_out, size_t go_bs,
                                                                             const int *__restrict__ idx,
                                                                             const float *__restrict__ weight,
                                                                             float *__restrict__ grad_points) {
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void three_interp_batch_bwd_atomic_kernel(int 
     if (pt >= n) return;
     const int ci = blockIdx.y, bs = blockIdx.z;
     const size_t o = ((size_t)bs * n + pt) * 3;
-    const float gv = grad_out[((size_t)bs * c + ci) * n + pt];
+    const float gv = grad_out[(size_t)bs * go_bs + (size_t)ci * n + pt];
     float *G = grad_points + ((size_t)bs * c + ci) * m;
     atomicAdd(G + idx[o + 0], gv * weight[o + 0]);
     atomicAdd(G + idx[o + 1], gv * weight[o + 1]);
@@ -460,9 +460,14 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_bat
     return three_interpolate_batch_impl<bf16_t>(b, c, m, n, (const bf16_t *)points, idx, weight, (bf16_t *)out, stream);
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
+// grad_out_bstride: elements between consecutive samples of grad_out (>= c * n): grad_out may be a channel slice of a wider
+// (b, c_total, n) tensor -- the gradient of the decoder's torch.cat([interpolated, skip]) -- read in place, no copy
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_batch_strided(int b, int c, int n, int m, const float *grad_out,
+                                                 long long grad_out_bstride, const int *idx,
                                                  const float *weight, float *grad_points, void *stream) {
     MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad_batch: negative size");
+    MGAR_REQUIRE(grad_out_bstride >= (long long)c * n, "three_interpolate_grad_batch: grad_out batch stride smaller than a sample");
+    const size_t go_bs = (size_t)grad_out_bstride;
     MGAR_REQUIRE(b <= 65535 && c <= 65535, "three_interpolate_grad_batch: b or c > 65535");
     if ((long long)b * c * n == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_out && idx && weight && grad_points, "three_interpolate_grad_batch: null pointer");
@@ -480,13 +485,17 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
         // keep enough workgroups in flight: at least ~2 per CU
         while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
         hipLaunchKernelGGL(three_interp_batch_bwd_lds_kernel, dim3(ceil_div(c, ch), b), dim3(threads),
-                           (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, n, m, ch, grad_out, idx, weight, grad_points);
+                           (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, n, m, ch, grad_out, go_bs, idx, weight, grad_points);
     } else {
         dim3 grid(ceil_div(n, 256), c, b);
         hipLaunchKernelGGL(three_interp_batch_bwd_atomic_kernel, grid, dim3(256), 0, (hipStream_t)stream, c, n, m,
-                           grad_out, idx, weight, grad_points);
+                           grad_out, go_bs, idx, weight, grad_points);
     }
     return check_launch("three_interpolate_grad_batch: launch failed");
+}
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                                 const float *weight, float *grad_points, void *stream) {
+    return mgar_three_interpolate_grad_batch_strided(b, c, n, m, grad_out, (long long)c * n, idx, weight, grad_points, stream);
 }
 
 template <typename T>
@@ -522,7 +531,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
 }
 
 template <int CH>
-static void launch_bwd_sorted(int b, int c, int n, int m, const float *grad_out, const int *list, float *grad_points,
+static void launch_bwd_sorted(int b, int c, int n, int m, const float *grad_out, size_t go_bs, const int *list, float *grad_points,
                               hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -531,14 +540,19 @@ static void launch_bwd_sorted(int b, int c, int n, int m, const float *grad_out,
         attr_set = true;
     }
     hipLaunchKernelGGL((mgar::three_interp_batch_bwd_sorted_kernel<CH>), dim3(ceil_div(c, CH), b), dim3(n >= 1024 ? 1024 : 256),
-                       (size_t)CH * n * sizeof(float), st, c, n, m, grad_out, reinterpret_cast<const int2 *>(list), grad_points);
+                       (size_t)CH * n * sizeof(float), st, c, n, m, grad_out, go_bs, reinterpret_cast<const int2 *>(list), grad_points);
 }
 
-extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m,
-                                                                                               const float *grad_out,
-                                                                                               const int *list,
-                                                                                               float *grad_points, void *stream) {
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_sorted_batch_strided(int b, int c, int n, int m,
+                                                                                                       const float *grad_out,
+                                                                                                       long long grad_out_bstride,
+                                                                                                       const int *list,
+                                                                                                       float *grad_points, void *stream) {
     MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad_sorted_batch: negative size");
+    MGAR_REQUIRE(grad_out_bstride >= (long long)c * n, "three_interpolate_grad_sorted_batch: grad_out batch stride smaller than a sample");
+    MGAR_REQUIRE((n & 3) != 0 || (grad_out_bstride % 4 == 0 && (uintptr_t)grad_out % 16 == 0),
+                 "three_interpolate_grad_sorted_batch: grad_out slice not 16-byte aligned");
+    const size_t go_bs = (size_t)grad_out_bstride;
     MGAR_REQUIRE(b <= 65535, "three_interpolate_grad_sorted_batch: b > 65535");
     if ((long long)b * c * n == 0 || m == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_out && list && grad_points, "three_interpolate_grad_sorted_batch: null pointer");
@@ -551,9 +565,15 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_gra
     while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
     hipStream_t st = (hipStream_t)stream;
     KtScope kt(KT_THREE_INTERP_BWD, st, (double)b * (24.0 * n + 4.0 * c * m + 4.0 * c * n));   // grad_out once, grad_points once, the 3n-entry list
-    if (ch == 8) launch_bwd_sorted<8>(b, c, n, m, grad_out, list, grad_points, st);
-    else if (ch == 4) launch_bwd_sorted<4>(b, c, n, m, grad_out, list, grad_points, st);
-    else if (ch == 2) launch_bwd_sorted<2>(b, c, n, m, grad_out, list, grad_points, st);
-    else launch_bwd_sorted<1>(b, c, n, m, grad_out, list, grad_points, st);
+    if (ch == 8) launch_bwd_sorted<8>(b, c, n, m, grad_out, go_bs, list, grad_points, st);
+    else if (ch == 4) launch_bwd_sorted<4>(b, c, n, m, grad_out, go_bs, list, grad_points, st);
+    else if (ch == 2) launch_bwd_sorted<2>(b, c, n, m, grad_out, go_bs, list, grad_points, st);
+    else launch_bwd_sorted<1>(b, c, n, m, grad_out, go_bs, list, grad_points, st);
     return check_launch("three_interpolate_grad_sorted_batch: launch failed");
+}
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m,
+                                                                                               const float *grad_out,
+                                                                                               const int *list,
+                                                                                               float *grad_points, void *stream) {
+    return mgar_three_interpolate_grad_sorted_batch_strided(b, c, n, m, grad_out, (long long)c * n, list, grad_points, stream);
 }

@@ -104,7 +104,10 @@ class Unit3D(nn.Module):
                        L.stream_of(x))
         return y
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """``out`` (optional): a channel slice y[:, c0:c1] of a wider tensor the result should land in (the caller's
+        concatenation); honoured where the fused BatchNorm + ReLU kernel writes the result, ignored otherwise --
+        the caller checks ``result is out``."""
         pads = _same_pads(x.shape[2:], self._kernel_shape, self._stride)
         stem = self._stem_conv(x)
         if stem is not None:
@@ -123,10 +126,10 @@ class Unit3D(nn.Module):
                 relu_fused = self._activation_fn is F.relu
                 if self.per_sample_stats and x.shape[0] > 1:
                     # several clips in one pass, each normalised with its own statistics = one pass per clip
-                    y = bn_ops.bn_act_per_sample(x, self.bn, relu_fused)
+                    y = bn_ops.bn_act_per_sample(x, self.bn, relu_fused, out=out)
                     assert y is not None, "per_sample_stats is a forward-only (frozen backbone) device path"
                 else:
-                    y = bn_ops.bn_act(x, self.bn, relu_fused)
+                    y = bn_ops.bn_act(x, self.bn, relu_fused, out=out)
             x = self.bn(x) if y is None else y
             relu_fused = relu_fused and y is not None
         if self._activation_fn is not None and not relu_fused:
@@ -148,6 +151,23 @@ class InceptionModule(nn.Module):
         self.name = name
 
     def forward(self, x):
+        if x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad):
+            # frozen backbone on the device: every branch's last BatchNorm + ReLU writes its channels of the concatenated
+            # output directly (csrc/bn_act.hip, mgar_bn_act_fwd_into): the torch.cat pass (a read and a write of the whole
+            # module output, 3.6 ms per step at config c3) disappears
+            ends = (self.b0, self.b1b, self.b2b, self.b3b)
+            widths = [u.conv3d.out_channels for u in ends]
+            dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
+            y = torch.empty((x.shape[0], sum(widths)) + tuple(x.shape[2:]), dtype=dt, device=x.device)   # 1x1x1 / "same" 3x3x3, stride 1
+            c0 = 0
+            for k, (unit, w) in enumerate(zip(ends, widths)):
+                h = x if k == 0 else (self.b1a(x) if k == 1 else (self.b2a(x) if k == 2 else self.b3a(x)))
+                dst = y[:, c0:c0 + w]
+                r = unit(h, out=dst)
+                if r is not dst:                                 # a path that did not take `out` (shape / dtype / layout): one copy
+                    dst.copy_(r)
+                c0 += w
+            return y
         return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
 
 

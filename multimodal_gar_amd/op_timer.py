@@ -10,6 +10,8 @@ and the WHOLE step is accounted for (52 % of the step had no rooflin
 Only meaningful for an eager, single-stream step (as bench.py issues its instrumented step): the time between an op's
 two events is then the time of the kernels that op launched.
 """
+import os
+
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 from torch.utils.flop_counter import flop_registry
@@ -21,6 +23,9 @@ _GEMM = ("mm", "addmm", "bmm", "baddbmm", "_scaled_mm")
 _NO_KERNEL = frozenset(("empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided", "resize_", "set_", "detach",
                         "alias", "_unsafe_view", "lift_fresh", "is_same_size", "_local_scalar_dense", "item", "sym_size",
                         "sym_numel", "sym_stride", "record_stream", "is_pinned", "_pin_memory"))
+
+
+_ALL_SHAPES = bool(os.environ.get("MGAR_OPTIMER_ALL_SHAPES"))   # diagnostics: one row per (op, shapes) for every aten op
 
 
 def _shapes(args):
@@ -59,6 +64,8 @@ class AtenOpTimer(TorchDispatchMode):
                 if torch.is_tensor(a) and a.is_floating_point():
                     dtype = a.dtype
                     break
+        if not key and _ALL_SHAPES:
+            key = _shapes(args)
         self.records.append((name, cls, key, flops, dtype, ev0, ev1))
         return out
 
@@ -112,6 +119,7 @@ KERNEL_SOURCES = {
     "ball_query_kernel": "ball_query.hip", "three_nn_kernel": "interpolate.hip", "three_interp_fwd": "interpolate.hip",
     "three_interp_bwd": "interpolate.hip", "query_group_fwd": "query_group.hip", "query_group_bwd": "query_group.hip",
     "voxel_roi_pool_fwd": "voxel_roi_pool.hip", "voxel_roi_pool_bwd": "voxel_roi_pool.hip", "stem_conv3d_kernel": "stem_conv.hip",
+    "query_group_inverse_index": "query_group.hip",
 }
 
 

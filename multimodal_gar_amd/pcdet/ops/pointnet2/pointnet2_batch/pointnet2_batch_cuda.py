@@ -77,8 +77,19 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     return 1
 
 
-def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
-    L.call("mgar_three_interpolate_grad_batch", b, c, n, m, L.fptr(grad_out), L.iptr(idx), L.fptr(weight),
+def _sliced_ptr(t, bstride):
+    """Pointer of a (b, c, n) float32 device tensor whose samples are `bstride` elements apart (a channel slice of a wider
+    contiguous tensor), or of a contiguous one (bstride None)."""
+    import torch
+    if bstride is None:
+        return L.fptr(t), t.shape[1] * t.shape[2]
+    assert t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) == t.shape[2] and t.stride(0) == bstride
+    return t.data_ptr(), bstride
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points, grad_out_bstride=None):
+    ptr, bs = _sliced_ptr(grad_out, grad_out_bstride)
+    L.call("mgar_three_interpolate_grad_batch_strided", b, c, n, m, ptr, bs, L.iptr(idx), L.fptr(weight),
            L.fptr(grad_points), L.stream_of(grad_out))
     return 1
 
@@ -110,7 +121,8 @@ def query_group_proj_grad_wrapper(b, c, n, npoints, nsample, grad_y, idx, grad_z
     return 1
 
 
-def three_interpolate_grad_sorted_wrapper(b, c, n, m, grad_out, entries, grad_points):
-    L.call("mgar_three_interpolate_grad_sorted_batch", b, c, n, m, L.fptr(grad_out), L.iptr(entries), L.fptr(grad_points),
+def three_interpolate_grad_sorted_wrapper(b, c, n, m, grad_out, entries, grad_points, grad_out_bstride=None):
+    ptr, bs = _sliced_ptr(grad_out, grad_out_bstride)
+    L.call("mgar_three_interpolate_grad_sorted_batch_strided", b, c, n, m, ptr, bs, L.iptr(entries), L.fptr(grad_points),
            L.stream_of(grad_out))
     return 1

@@ -129,7 +129,16 @@ class ThreeInterpolate(Function):
         idx, weight = ctx.saved_tensors
         batch, chans, n_unknown = grad_out.size()
         grad_features = _new(grad_out, (batch, chans, ctx.n_known), torch.float32, 0.0)
-        grad_out = grad_out.contiguous()
+        # the gradient of the decoder's torch.cat([interpolated, skip]) arrives as a CHANNEL SLICE of the wider tensor: the
+        # device kernels read it in place (batch stride), where the reference copies it (up to 2 GB per launch at c3)
+        bstride = None
+        if grad_out.is_cuda and grad_out.dtype == torch.float32 and not grad_out.is_contiguous() and grad_out.stride(2) == 1 \
+                and grad_out.stride(1) == n_unknown and grad_out.stride(0) >= chans * n_unknown \
+                and (n_unknown % 4 != 0 or (grad_out.stride(0) % 4 == 0 and grad_out.data_ptr() % 16 == 0)) \
+                and hasattr(pointnet2, "_sliced_ptr"):
+            bstride = grad_out.stride(0)
+        else:
+            grad_out = grad_out.contiguous()
         m = ctx.n_known
         if grad_out.is_cuda and n_unknown <= 36864 and m <= 65535 and chans >= 16 and hasattr(pointnet2, "three_interpolate_grad_sorted_wrapper"):
             # inverted index: the 3n entries of every cloud sorted (stable) by known point, built once and
@@ -139,7 +148,9 @@ class ThreeInterpolate(Function):
             order = torch.argsort(key.view(-1), stable=True)
             packed = (idx.view(-1)[order] << 16) | ((order // 3) % n_unknown).int()
             entries = torch.stack((packed, weight.reshape(-1)[order].view(torch.int32)), dim=1).contiguous()
-            pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features)
+            pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features, bstride)
+        elif bstride is not None:
+            pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, ctx.n_known, grad_out, idx, weight, grad_features, bstride)
         else:
             pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, ctx.n_known, grad_out, idx, weight, grad_features)
         return grad_features, None, None
