@@ -127,6 +127,10 @@ int mgar_three_interpolate_grad_batch(int b, int c, int n, int m, const float *g
  * summation order. */
 int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m, const float *grad_out, const int *list,
                                              float *grad_points, void *stream);
+/* Forward with out a CHANNEL SLICE of a wider (b, c_total, n) tensor (samples out_bstride >= c * n elements apart): the
+ * interpolated half of the decoder's torch.cat([interpolated, skip]) is written where the concatenation wants it. */
+int mgar_three_interpolate_batch_into(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                      float *out, long long out_bstride, void *stream);
 /* Both with grad_out a CHANNEL SLICE of a wider (b, c_total, n) tensor: consecutive samples are grad_out_bstride >= c * n
  * elements apart.  The decoder (reference PointnetFPModule, pointnet2_batch/pointnet2_modules.py:139-148) concatenates the
  * interpolated features with the skip features; the gradient of that torch.cat hands this op a slice, which the reference's
@@ -542,6 +546,8 @@ int mgar_bn_train_stats_grouped_bf16(const void *x, int G, int C, int P, float e
 /* x, y */
 int mgar_bn_act_fwd_bf16(const void *x, int B, int C, int P, const float *mean, const float *invstd,
                          const float *gamma, const float *beta, int relu, void *y, void *stream);
+int mgar_three_interpolate_batch_into_bf16(int b, int c, int m, int n, const void *points, const int *idx, const float *weight,
+                                           void *out, long long out_bstride, void *stream);
 int mgar_bn_act_fwd_into_bf16(const void *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
                               const float *beta, int relu, int stats_per_sample, void *y, long long y_bstride, void *stream);
 int mgar_bn_act_fwd_grouped_bf16(const void *x, int G, int C, int P, const float *mean, const float *invstd,

@@ -121,14 +121,14 @@ __global__ __launch_bounds__(1024) void three_interp_batch_fwd_lds_kernel(int c,
                                                                           const T *__restrict__ points,
                                                                           const int *__restrict__ idx,
                                                                           const float *__restrict__ weight,
-                                                                          T *__restrict__ out) {
+                                                                          T *__restrict__ out, size_t out_bs) {
     extern __shared__ float rows[];  // [CH][m]
     const int c0 = blockIdx.x * CH, bs = blockIdx.y;
     const int nch = min(CH, c - c0);
     const T *src = points + ((size_t)bs * c + c0) * m;
     for (int i = threadIdx.x; i < nch * m; i += blockDim.x) rows[i] = Payload<T>::ld(src + i);
     __syncthreads();
-    T *dst = out + ((size_t)bs * c + c0) * n;
+    T *dst = out + (size_t)bs * out_bs + (size_t)c0 * n;
     for (int pt = threadIdx.x; pt < n; pt += blockDim.x) {
         const size_t o = ((size_t)bs * n + pt) * 3;
         const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int 
                                                                      const T *__restrict__ points,
                                                                      const int *__restrict__ idx,
                                                                      const float *__restrict__ weight,
-                                                                     T *__restrict__ out) {
+                                                                     T *__restrict__ out, size_t out_bs) {
     const int pt = blockIdx.x * 256 + threadIdx.x;
     if (pt >= n) return;
     const int bs = blockIdx.z;
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int 
     const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
     const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
     const T *src = points + ((size_t)bs * c + c0) * m;
-    T *dst = out + ((size_t)bs * c + c0) * n + pt;
+    T *dst = out + (size_t)bs * out_bs + (size_t)c0 * n + pt;
     for (int ci = c0; ci < c1; ++ci) {
         Payload<T>::st(dst, dot3_of(w0, Payload<T>::ld(src + i0), w1, Payload<T>::ld(src + i1), w2, Payload<T>::ld(src + i2)));
         src += m;
@@ -423,8 +423,11 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_nn_stack(int ba
 
 template <typename T>
 static int three_interpolate_batch_impl(int b, int c, int m, int n, const T *points, const int *idx, const float *weight, T *out,
-                                        void *stream) {
+                                        void *stream, long long out_bstride = -1) {
     MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_batch: negative size");
+    if (out_bstride < 0) out_bstride = (long long)c * n;
+    MGAR_REQUIRE(out_bstride >= (long long)c * n, "three_interpolate_batch: output batch stride smaller than a sample");
+    const size_t out_bs = (size_t)out_bstride;
     MGAR_REQUIRE(b <= 65535, "three_interpolate_batch: b > 65535");
     if ((long long)b * c * n == 0) return MGAR_OK;
     MGAR_REQUIRE(points && idx && weight && out, "three_interpolate_batch: null pointer");
@@ -441,11 +444,11 @@ static int three_interpolate_batch_impl(int b, int c, int m, int n, const T *poi
         ch = ch > 8 ? 8 : ch;
         while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
         hipLaunchKernelGGL(three_interp_batch_fwd_lds_kernel<T>, dim3(ceil_div(c, ch), b), dim3(n >= 4096 ? 1024 : 256),
-                           (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, m, n, ch, points, idx, weight, out);
+                           (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, m, n, ch, points, idx, weight, out, out_bs);
     } else {
         dim3 grid(ceil_div(n, 256), ceil_div(c, TI_CCHUNK), b);
         hipLaunchKernelGGL(three_interp_batch_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx,
-                           weight, out);
+                           weight, out, out_bs);
     }
     return check_launch("three_interpolate_batch: launch failed");
 }
@@ -458,6 +461,17 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_bat
 extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_bf16(int b, int c, int m, int n, const void *points, const int *idx,
                                             const float *weight, void *out, void *stream) {
     return three_interpolate_batch_impl<bf16_t>(b, c, m, n, (const bf16_t *)points, idx, weight, (bf16_t *)out, stream);
+}
+
+// out a CHANNEL SLICE of a wider (b, c_total, n) tensor (samples out_bstride >= c * n elements apart): the decoder's
+// torch.cat([interpolated, skip]) without the pass that copies the interpolated half
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_into(int b, int c, int m, int n, const float *points, const int *idx,
+                                            const float *weight, float *out, long long out_bstride, void *stream) {
+    return three_interpolate_batch_impl<float>(b, c, m, n, points, idx, weight, out, stream, out_bstride);
+}
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_into_bf16(int b, int c, int m, int n, const void *points, const int *idx,
+                                            const float *weight, void *out, long long out_bstride, void *stream) {
+    return three_interpolate_batch_impl<bf16_t>(b, c, m, n, (const bf16_t *)points, idx, weight, (bf16_t *)out, stream, out_bstride);
 }
 
 // grad_out_bstride: elements between consecutive samples of grad_out (>= c * n): grad_out may be a channel slice of a wider

@@ -77,6 +77,14 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     return 1
 
 
+def three_interpolate_into_wrapper(b, c, m, n, points, idx, weight, merged):
+    """three_interpolate into the first c channels of merged (b, c_total, n) (contiguous)."""
+    dt = points.dtype
+    L.payload_call("mgar_three_interpolate_batch_into", dt, b, c, m, n, L.pptr(points, dt), L.iptr(idx), L.fptr(weight), L.pptr(merged, dt),
+                   merged.shape[1] * merged.shape[2], L.stream_of(points))
+    return 1
+
+
 def _sliced_ptr(t, bstride):
     """Pointer of a (b, c, n) float32 device tensor whose samples are `bstride` elements apart (a channel slice of a wider
     contiguous tensor), or of a contiguous one (bstride None)."""

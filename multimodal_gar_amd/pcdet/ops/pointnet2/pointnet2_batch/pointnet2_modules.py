@@ -136,6 +136,10 @@ class PointnetFPModule(nn.Module):
         """``nn_weights``: neighbour_weights(unknown, known) computed ahead of time by the caller (same values)."""
         if known is not None:
             idx, weight = nn_weights if nn_weights is not None else self.neighbour_weights(unknown, known)
+            if unknow_feats is not None and known_feats.is_cuda:
+                # interpolation written straight into the concatenated tensor (no copy of the interpolated half)
+                merged = pointnet2_utils.three_interpolate_concat(known_feats, idx, weight, unknow_feats)
+                return self.mlp(merged.unsqueeze(-1)).squeeze(-1)
             spread = pointnet2_utils.three_interpolate(known_feats, idx, weight)
         else:
             spread = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))

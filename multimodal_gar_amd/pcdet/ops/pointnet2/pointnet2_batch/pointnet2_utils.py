@@ -127,36 +127,76 @@ class ThreeInterpolate(Function):
     @once_differentiable
     def backward(ctx, grad_out):
         idx, weight = ctx.saved_tensors
-        batch, chans, n_unknown = grad_out.size()
-        grad_features = _new(grad_out, (batch, chans, ctx.n_known), torch.float32, 0.0)
-        # the gradient of the decoder's torch.cat([interpolated, skip]) arrives as a CHANNEL SLICE of the wider tensor: the
-        # device kernels read it in place (batch stride), where the reference copies it (up to 2 GB per launch at c3)
-        bstride = None
-        if grad_out.is_cuda and grad_out.dtype == torch.float32 and not grad_out.is_contiguous() and grad_out.stride(2) == 1 \
-                and grad_out.stride(1) == n_unknown and grad_out.stride(0) >= chans * n_unknown \
-                and (n_unknown % 4 != 0 or (grad_out.stride(0) % 4 == 0 and grad_out.data_ptr() % 16 == 0)) \
-                and hasattr(pointnet2, "_sliced_ptr"):
-            bstride = grad_out.stride(0)
-        else:
-            grad_out = grad_out.contiguous()
-        m = ctx.n_known
-        if grad_out.is_cuda and n_unknown <= 36864 and m <= 65535 and chans >= 16 and hasattr(pointnet2, "three_interpolate_grad_sorted_wrapper"):
-            # inverted index: the 3n entries of every cloud sorted (stable) by known point, built once and
-            # shared by all channels -- every known point is then summed by one owner, without atomics
-            key = idx + (torch.arange(batch, device=idx.device, dtype=torch.int32) * m).view(-1, 1, 1) \
-                if batch * m < 2 ** 31 else idx.long() + (torch.arange(batch, device=idx.device) * m).view(-1, 1, 1)
-            order = torch.argsort(key.view(-1), stable=True)
-            packed = (idx.view(-1)[order] << 16) | ((order // 3) % n_unknown).int()
-            entries = torch.stack((packed, weight.reshape(-1)[order].view(torch.int32)), dim=1).contiguous()
-            pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features, bstride)
-        elif bstride is not None:
-            pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, ctx.n_known, grad_out, idx, weight, grad_features, bstride)
-        else:
-            pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, ctx.n_known, grad_out, idx, weight, grad_features)
-        return grad_features, None, None
+        return _three_interpolate_backward(grad_out, idx, weight, ctx.n_known), None, None
+
+
+def _three_interpolate_backward(grad_out, idx, weight, n_known):
+    """grad wrt the known features (B, C, m) from grad_out (B, C, n), which may be a CHANNEL SLICE of a wider tensor."""
+    batch, chans, n_unknown = grad_out.size()
+    grad_features = _new(grad_out, (batch, chans, n_known), torch.float32, 0.0)
+    # the gradient of the decoder's torch.cat([interpolated, skip]) arrives as a CHANNEL SLICE of the wider tensor: the
+    # device kernels read it in place (batch stride), where the reference copies it (up to 2 GB per launch at c3)
+    bstride = None
+    if grad_out.is_cuda and grad_out.dtype == torch.float32 and not grad_out.is_contiguous() and grad_out.stride(2) == 1 \
+            and grad_out.stride(1) == n_unknown and grad_out.stride(0) >= chans * n_unknown \
+            and (n_unknown % 4 != 0 or (grad_out.stride(0) % 4 == 0 and grad_out.data_ptr() % 16 == 0)) \
+            and hasattr(pointnet2, "_sliced_ptr"):
+        bstride = grad_out.stride(0)
+    else:
+        grad_out = grad_out.contiguous().float()
+    m = n_known
+    if grad_out.is_cuda and n_unknown <= 36864 and m <= 65535 and chans >= 16 and hasattr(pointnet2, "three_interpolate_grad_sorted_wrapper"):
+        # inverted index: the 3n entries of every cloud sorted (stable) by known point, built once and
+        # shared by all channels -- every known point is then summed by one owner, without atomics
+        key = idx + (torch.arange(batch, device=idx.device, dtype=torch.int32) * m).view(-1, 1, 1) \
+            if batch * m < 2 ** 31 else idx.long() + (torch.arange(batch, device=idx.device) * m).view(-1, 1, 1)
+        order = torch.argsort(key.view(-1), stable=True)
+        packed = (idx.view(-1)[order] << 16) | ((order // 3) % n_unknown).int()
+        entries = torch.stack((packed, weight.reshape(-1)[order].view(torch.int32)), dim=1).contiguous()
+        pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features, bstride)
+    elif bstride is not None:
+        pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, n_known, grad_out, idx, weight, grad_features, bstride)
+    else:
+        pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, n_known, grad_out, idx, weight, grad_features)
+    return grad_features
+
+
+class ThreeInterpolateConcat(Function):
+    """torch.cat([three_interpolate(features, idx, weight), skip], dim=1) with the interpolation written straight into its
+    channels of the result (csrc/interpolate.hip, mgar_three_interpolate_batch_into): the decoder step of the reference
+    (PointnetFPModule.forward, pointnet2_batch/pointnet2_modules.py:139-148) without the pass that copies the interpolated
+    half -- 2 GB of it at the finest level of config c3.  Device only."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight, skip):
+        assert features.is_cuda and features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous()
+        batch, chans, n_known = features.size()
+        n_unknown = idx.size(1)
+        merged = _new(features, (batch, chans + skip.shape[1], n_unknown), features.dtype)
+        pointnet2.three_interpolate_into_wrapper(batch, chans, n_known, n_unknown, features, idx, weight.float(), merged)
+        merged[:, chans:].copy_(skip)
+        ctx.save_for_backward(idx, weight)
+        ctx.dims = (n_known, chans)
+        return merged
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_merged):
+        idx, weight = ctx.saved_tensors
+        n_known, chans = ctx.dims
+        grad_merged = grad_merged.contiguous()
+        grad_features = _three_interpolate_backward(grad_merged[:, :chans], idx, weight, n_known) if ctx.needs_input_grad[0] else None
+        return grad_features, None, None, grad_merged[:, chans:] if ctx.needs_input_grad[3] else None
 
 
 three_interpolate = ThreeInterpolate.apply
+
+
+def three_interpolate_concat(features, idx, weight, skip):
+    """cat([three_interpolate(features, idx, weight), skip], 1); on the device in one pass over the interpolated half."""
+    if features.is_cuda and skip.dtype == features.dtype and hasattr(pointnet2, "three_interpolate_into_wrapper"):
+        return ThreeInterpolateConcat.apply(features.contiguous(), idx, weight, skip)
+    return torch.cat([three_interpolate(features, idx, weight), skip], dim=1)
 
 
 class GroupingOperation(Function):
