@@ -260,14 +260,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const T *__r
                                                                     int B, int C, int P, const float *__restrict__ mean,
                                                                     const float *__restrict__ invstd,
                                                                     const float *__restrict__ gamma,
-                                                                    const float *__restrict__ beta, float *__restrict__ partial) {
+                                                                    const float *__restrict__ beta, float *__restrict__ partial,
+                                                                    int chunk) {
     __shared__ float scratch[BN_THREADS / 64];
     const int c = blockIdx.y;
     const float mu = mean[c], is = invstd[c];
     const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
     const long long n = (long long)B * P;
-    const long long e0 = (long long)blockIdx.x * BN_CHUNK;
-    const long long e1 = min(e0 + BN_CHUNK, n);
+    const long long e0 = (long long)blockIdx.x * chunk;
+    const long long e1 = min(e0 + chunk, n);
     float s = 0.f, q = 0.f;
     const float sc = is * g;
     auto acc = [&](float xv, float d) {
@@ -313,13 +314,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_max_bwd_partial_kernel(const T 
                                                                         const T *__restrict__ xarg, int B, int C, int M, int NS,
                                                                         const float *__restrict__ mean,
                                                                         const float *__restrict__ invstd,
-                                                                        float *__restrict__ partial, DpoolStrides ds) {
+                                                                        float *__restrict__ partial, DpoolStrides ds, int chunk) {
     __shared__ float scratch[BN_THREADS / 64];
     const int c = blockIdx.y;
     const float mu = mean[c], is = invstd[c];
     const long long n = (long long)B * M;
-    const long long e0 = (long long)blockIdx.x * BN_CHUNK;
-    const long long e1 = min(e0 + BN_CHUNK, n);
+    const long long e0 = (long long)blockIdx.x * chunk;
+    const long long e1 = min(e0 + chunk, n);
     float s = 0.f, q = 0.f;
     for (long long e = e0 + threadIdx.x; e < e1; e += BN_THREADS) {
         const size_t o = chan_off(e, c, C, M);
@@ -474,6 +475,14 @@ static inline int bn_nchunk_fwd(int B, int C, long long P) {
     return (int)(((long long)B * P + chunk - 1) / chunk);
 }
 static inline int bn_nchunk(int B, int P) { return (int)(((long long)B * P + BN_CHUNK - 1) / BN_CHUNK); }
+// the BACKWARD reductions shrink their chunk the same way (round 2: at one clip per rank the fixed 65 536-element chunk left
+// 32 workgroups walking 61 440 elements each: 47-84 us per launch).  n = elements per channel of THIS reduction (B*P, or B*M
+// after a max-pool); never more chunks than mgar_bn_workspace_floats() reserves for the layer's (B, C, P).
+static inline int bn_chunk_bwd(int C, long long n) {
+    int chunk = BN_CHUNK;
+    while (chunk > 4096 && ((n + chunk - 1) / chunk) * C < 2048) chunk >>= 1;
+    return chunk;
+}
 
 }  // namespace mgar
 
@@ -483,7 +492,9 @@ using namespace mgar;
 
 BN_API int mgar_bn_workspace_floats(int B, int C, int P) {
     if (B < 0 || C < 0 || P < 0) return MGAR_EINVAL;
-    const int nc = bn_nchunk_fwd(B, C, P) > bn_nchunk(B, P) ? bn_nchunk_fwd(B, C, P) : bn_nchunk(B, P);
+    int nc = bn_nchunk_fwd(B, C, P) > bn_nchunk(B, P) ? bn_nchunk_fwd(B, C, P) : bn_nchunk(B, P);
+    const int small = 4096 / (C > 0 ? C : 1) + 2;   // bound of the chunk count of a reduction over fewer elements (bn_chunk_bwd)
+    if (nc < small) nc = small;
     return 2 * C * (nc > 0 ? nc : 1) + 2 * C;   // [partials | 2*C: bwd coefficients, or C: variances of the grouped statistics]
 }
 
@@ -610,12 +621,12 @@ static int bn_act_bwd_impl(const T *dy, const T *x, int B, int C, int P, const f
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx, "bn_act_bwd: null pointer");
     MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS, "bn_act_bwd: C > 65535 or P too large");
-    const int nchunk = bn_nchunk(B, P);
+    const int chunk = bn_chunk_bwd(C, (long long)B * P), nchunk = (int)(((long long)B * P + chunk - 1) / chunk);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_BWD_REDUCE, st, 2.0 * sizeof(T) * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace, chunk);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace, chunk);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
     dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
@@ -637,12 +648,12 @@ static int bn_act_maxpool_bwd_impl(const T *dpool, const T *pooled, const unsign
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(dpool && pooled && arg && x && mean && invstd && workspace && dx, "bn_act_maxpool_bwd: null pointer");
     MGAR_REQUIRE(C <= 65535 && (long long)M * nsample <= 65535LL * BN_THREADS, "bn_act_maxpool_bwd: C > 65535 or M*nsample too large");
-    const int nchunk = bn_nchunk(B, M);
+    const int chunk = bn_chunk_bwd(C, (long long)B * M), nchunk = (int)(((long long)B * M + chunk - 1) / chunk);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_MAX_BWD_REDUCE, st, (3.0 * sizeof(T) + 1.0) * (double)B * C * M);
-    if (relu) hipLaunchKernelGGL((bn_max_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace, ds);
-    else hipLaunchKernelGGL((bn_max_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace, ds);
+    if (relu) hipLaunchKernelGGL((bn_max_bwd_partial_kernel<true, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace, ds, chunk);
+    else hipLaunchKernelGGL((bn_max_bwd_partial_kernel<false, T>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, workspace, ds, chunk);
     }
     // the means are over ALL B*M*nsample elements of the channel, not only the arg-max ones
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * M * nsample, dgamma, dbeta, coef);
@@ -735,12 +746,12 @@ BN_API int mgar_bn_act_bwd_rowmajor(const float *dy, const float *x, int B, int 
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx_t, "bn_act_bwd_rowmajor: null pointer");
     MGAR_REQUIRE(B <= 65535, "bn_act_bwd_rowmajor: B > 65535");
-    const int nchunk = bn_nchunk(B, P);
+    const int chunk = bn_chunk_bwd(C, (long long)B * P), nchunk = (int)(((long long)B * P + chunk - 1) / chunk);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
     { KtScope kt(KT_BN_BWD_REDUCE, st, 8.0 * (double)B * C * P);
-    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, float>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
-    else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, float>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace);
+    if (relu) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, float>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace, chunk);
+    else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, float>), dim3(nchunk, C), dim3(BN_THREADS), 0, st, dy, x, B, C, P, mean, invstd, gamma, beta, workspace, chunk);
     }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)B * P, dgamma, dbeta, coef);
     dim3 grid(ceil_div(P, 64), B);

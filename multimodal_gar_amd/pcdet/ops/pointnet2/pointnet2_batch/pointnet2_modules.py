@@ -53,12 +53,13 @@ class _PointnetSAModuleBase(nn.Module):
                 if isinstance(grouper, pointnet2_utils.QueryAndGroup) and grouper.use_xyz and mlp.first_layer_foldable(3 + n_feat)]
 
     def ball_indices(self, xyz, new_xyz, n_feat):
-        """The ball queries of the folded scales in ONE scan of the cloud (they share centres and cloud) -> {scale: idx}.
-        Pure geometry: callable ahead of the features (model/../workload.py issues it on a side stream)."""
-        fold = self._fold_scales(n_feat, xyz.is_cuda)
-        if len(fold) > 1 and hasattr(pointnet2_utils.pointnet2, "ball_query_multi_wrapper"):
-            return dict(zip(fold, pointnet2_utils.ball_query_multi([self.groupers[k].radius for k in fold],
-                                                                   [self.groupers[k].nsample for k in fold], xyz, new_xyz)))
+        """The ball queries of all scales in ONE scan of the cloud (they share centres and cloud) -> {scale: idx}; device only.
+        Pure geometry: callable ahead of the features (model/../workload.py can issue it on a side stream)."""
+        del n_feat
+        scales = [k for k, g in enumerate(self.groupers) if isinstance(g, pointnet2_utils.QueryAndGroup)] if xyz.is_cuda else []
+        if len(scales) > 1 and hasattr(pointnet2_utils.pointnet2, "ball_query_multi_wrapper"):
+            return dict(zip(scales, pointnet2_utils.ball_query_multi([self.groupers[k].radius for k in scales],
+                                                                     [self.groupers[k].nsample for k in scales], xyz, new_xyz)))
         return {}
 
     def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None,
@@ -79,7 +80,7 @@ class _PointnetSAModuleBase(nn.Module):
                 y0 = grouper.forward_projected(xyz, new_xyz, features, mlp[0].weight, idx=pre_idx.get(k))
                 per_scale.append(mlp.forward_maxpool(y0, start=1))
                 continue
-            grouped = grouper(xyz, new_xyz, features)          # (B, C', npoint, nsample)
+            grouped = grouper(xyz, new_xyz, features, idx=pre_idx[k]) if k in pre_idx else grouper(xyz, new_xyz, features)   # (B, C', npoint, nsample)
             if self.pool_method == 'max_pool':
                 per_scale.append(mlp.forward_maxpool(grouped))             # BN + ReLU + max fused on the device
             else:

@@ -333,8 +333,10 @@ class QueryAndGroup(nn.Module):
         super().__init__()
         self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
 
-    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
-        idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: Optional[torch.Tensor] = None, idx=None):
+        """``idx``: this ball query's result computed ahead by the caller (the scales of an MSG module share one scan)."""
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
         if features is None:
             assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
         if not self.use_xyz:
