@@ -247,6 +247,12 @@ int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int nsampl
 int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
                                     const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, int zf_ld,
                                     const float *wx, const int *idx, float *rel_out, float *y_out, void *stream);
+/* ..._fwd that also leaves the statistics partials of y_out for the BatchNorm that follows: out_stats (C, M*nsample/128, 2),
+ * chunk = 128 (M * nsample % 128 == 0). */
+int mgar_query_group_proj_stack_fwd_stats(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                          const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, int zf_ld,
+                                          const float *wx, const int *idx, float *rel_out, float *y_out, float *out_stats,
+                                          void *stream);
 int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,
                                     const int *new_xyz_batch_cnt, const int *xyz_batch_cnt, float *grad_zf,
                                     int zf_ld, void *stream);
@@ -325,6 +331,14 @@ int mgar_bn_act_maxpool_fwd(const float *x, int B, int C, int M, int nsample, co
 int mgar_bn_act_bwd(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *workspace, float *dgamma,
                     float *dbeta, float *dx, void *stream);
+/* BatchNorm training statistics from partials a PRODUCER kernel left behind (mgar_pointwise_conv_fwd_stats,
+ * mgar_query_group_proj_stack_fwd_stats): partial (C, nchunk, 2) = per (channel, chunk of `chunk` consecutive elements of the
+ * channel in (b, p) order) the chunk's mean and sum of squared deviations; n = elements per channel.  The finalize of
+ * mgar_bn_train_stats (merge in double, running statistics) without its pass over the tensor (4 * B * C * P bytes). */
+long long mgar_bn_stats_from_partials_workspace_floats(int nchunk, int C);
+int mgar_bn_stats_from_partials(const float *partial, int nchunk, int C, long long n, int chunk, float eps, float momentum,
+                                float *workspace, float *mean, float *invstd, float *running_mean, float *running_var,
+                                long long *num_batches_tracked, void *stream);
 /* mgar_bn_act_maxpool_bwd with dpool read IN PLACE from a strided tensor: element (b, c, m) at dpool[b*sb + c*sc + m*sm]
  * -- a channel slice of a wider (B, C_total, M) tensor (gradient of the torch.cat over the scales of an SA module,
  * reference pointnet2_modules.py:55) or the transposed view of (M, C_total) rows -- instead of a copy first. */
@@ -369,6 +383,11 @@ int mgar_pointwise_conv_dw_act(const float *x, const float *dy, int B, int Cin, 
 int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *w, int w_row_stride,
                             int w_col_stride, int Cout, const float *in_mean, const float *in_invstd,
                             const float *in_gamma, const float *in_beta, int in_relu, float *y, void *stream);
+/* The same, also leaving the statistics partials of y for the BatchNorm that follows: out_stats (Cout, B * P / 128, 2),
+ * chunk = 128 (mgar_bn_stats_from_partials).  P % 128 == 0, Cout <= 32 (MGAR_EUNSUPPORTED otherwise). */
+int mgar_pointwise_conv_fwd_stats(const float *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride,
+                                  int Cout, const float *in_mean, const float *in_invstd, const float *in_gamma,
+                                  const float *in_beta, int in_relu, float *y, float *out_stats, void *stream);
 
 /* MaxPool3dSamePadding.forward of the reference's I3D (model/backbone.py:99-131): zero "same"
  * padding + max pooling without materialising the padded tensor.  x (NC, T, H, W) -> y (NC, ceil(T/st),

@@ -70,6 +70,10 @@ _PROTOS = {
     "mgar_bn_act_fwd": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_bn_act_maxpool_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P],
     "mgar_bn_act_bwd": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_stats_from_partials_workspace_floats": [_I, _I],
+    "mgar_bn_stats_from_partials": [_P, _I, _I, _LL, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_pointwise_conv_fwd_stats": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
+    "mgar_query_group_proj_stack_fwd_stats": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "mgar_bn_act_maxpool_bwd_strided": [_P, _LL, _LL, _LL, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_bn_act_fwd_into": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _LL, _P],
     "mgar_bn_act_bwd_rowmajor": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
@@ -119,7 +123,7 @@ _fns = {}
 for _name, _args in _PROTOS.items():
     _fn = getattr(_cdll, _name)  # AttributeError here = the library is stale: rebuild it
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats", "_inverse_items", "_workspace_ints")) else ctypes.c_int
+    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats", "_inverse_items", "_workspace_ints", "_partials_workspace_floats")) else ctypes.c_int
     _fns[_name] = _fn
 
 _cdll.mgar_abi_version.restype = ctypes.c_int

@@ -27,11 +27,32 @@ def _f32(t):
     return t if t is None or t.dtype == torch.float32 else t.float()
 
 
-def _train_stats(x3, bn):
+STATS_TILE = 128   # columns per statistics partial of the producer kernels (csrc/pointwise_fwd.hip, csrc/query_group.hip)
+
+
+def stats_partial_buffer(x_like, c, n_per_channel):
+    """Buffer a producer kernel fills with the BatchNorm statistics partials of its output -- (C, n / 128, 2): per channel
+    and 128-column tile the tile's mean and sum of squared deviations -- or None where that does not apply (n % 128, dtype)."""
+    if x_like.dtype != torch.float32 or not x_like.is_cuda or n_per_channel % STATS_TILE != 0 or n_per_channel == 0:
+        return None
+    return torch.empty((c, n_per_channel // STATS_TILE, 2), dtype=torch.float32, device=x_like.device)
+
+
+def _train_stats(x3, bn, partial=None):
     b, c, p = x3.shape
     mean = torch.empty((c,), dtype=torch.float32, device=x3.device)
     invstd = torch.empty_like(mean)
     track = bn.track_running_stats and bn.running_mean is not None
+    if partial is not None and tuple(partial.shape) == (c, (b * p) // STATS_TILE, 2) and (b * p) % STATS_TILE == 0:
+        # the producer of x left the per-tile (mean, M2): merge them, no pass over x (csrc/bn_act.hip, bn_finalize_kernel)
+        nws = L.raw("mgar_bn_stats_from_partials_workspace_floats", partial.shape[1], c)
+        ws = torch.empty((nws,), dtype=torch.float32, device=x3.device) if nws else None
+        L.call("mgar_bn_stats_from_partials", L.fptr(partial), partial.shape[1], c, b * p, STATS_TILE, float(bn.eps),
+               float(bn.momentum if bn.momentum is not None else 0.1), L.fptr(ws) if ws is not None else None, L.fptr(mean), L.fptr(invstd),
+               L.fptr(bn.running_mean) if track else None, L.fptr(bn.running_var) if track else None,
+               L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
+               L.stream_of(x3))
+        return mean, invstd
     ws = _workspace(x3, b, c, p)
     L.payload_call("mgar_bn_train_stats", x3.dtype, L.pptr(x3, x3.dtype), b, c, p, float(bn.eps),
                    float(bn.momentum if bn.momentum is not None else 0.1),
@@ -137,15 +158,20 @@ class _BnActConv(Function):
     gradient kernel (csrc/pointwise_dw.hip); only the pre-BN x is saved."""
 
     @staticmethod
-    def forward(ctx, x3, gamma, beta, mean, invstd, relu, w, rowmajor_grad=False):
+    def forward(ctx, x3, gamma, beta, mean, invstd, relu, w, rowmajor_grad=False, out_stats=None):
+        """out_stats (optional, stats_partial_buffer(y)): filled with the statistics partials of y for the BatchNorm that follows."""
         b, c, p = x3.shape
         ctx.rowmajor = bool(rowmajor_grad) and x3.dtype == torch.float32 and c <= ROWMAJOR_GRAD_MAX_CHANNELS
         cout = w.shape[0]
         w = w.contiguous()
         dt = x3.dtype
         y = torch.empty((b, cout, p), dtype=dt, device=x3.device)
-        L.payload_call("mgar_pointwise_conv_fwd", dt, L.pptr(x3, dt), b, c, p, L.fptr(w), c, 1, cout, L.fptr(mean), L.fptr(invstd),
-                       L.fptr(gamma), L.fptr(beta), int(relu), L.pptr(y, dt), L.stream_of(x3))
+        if out_stats is not None:
+            L.call("mgar_pointwise_conv_fwd_stats", L.fptr(x3), b, c, p, L.fptr(w), c, 1, cout, L.fptr(mean), L.fptr(invstd),
+                   L.fptr(gamma), L.fptr(beta), int(relu), L.fptr(y), L.fptr(out_stats), L.stream_of(x3))
+        else:
+            L.payload_call("mgar_pointwise_conv_fwd", dt, L.pptr(x3, dt), b, c, p, L.fptr(w), c, 1, cout, L.fptr(mean), L.fptr(invstd),
+                           L.fptr(gamma), L.fptr(beta), int(relu), L.pptr(y, dt), L.stream_of(x3))
         ctx.save_for_backward(x3, gamma, beta, mean, invstd, w)
         ctx.relu = relu
         return y
@@ -172,17 +198,20 @@ class _BnActConv(Function):
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = _workspace(x3, b, c, p)
         if ctx.rowmajor:
-            return _bwd_rowmajor(ga, x3, mean, invstd, gamma, beta, ctx.relu, ws, dgamma, dbeta), dgamma, dbeta, None, None, None, dw, None
+            return _bwd_rowmajor(ga, x3, mean, invstd, gamma, beta, ctx.relu, ws, dgamma, dbeta), dgamma, dbeta, None, None, None, dw, None, None
         dx = torch.empty_like(x3)
         L.call("mgar_bn_act_bwd", L.fptr(ga), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma),
                L.fptr(beta), int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), st)
-        return dx, dgamma, dbeta, None, None, None, dw, None
+        return dx, dgamma, dbeta, None, None, None, dw, None, None
 
 
 FUSED_CONV_MAX_CHANNELS = 64   # csrc/pointwise_fwd.hip: Cout <= 64 in both directions
 
 
-def bn_act_conv(x, bn, relu, conv, rowmajor_grad=False):
+FUSED_STATS_MAX_CHANNELS = 32   # csrc/pointwise_fwd.hip: the statistics epilogue exists for Cout <= 32
+
+
+def bn_act_conv(x, bn, relu, conv, rowmajor_grad=False, in_stats=None, want_out_stats=False):
     """conv(relu?(bn(x))) for a bias-free kernel-size-1 ``conv`` in one fused step, or None if the
     shapes are outside the fused kernel (the caller then runs bn_act and the GEMM separately)."""
     if not (x.is_cuda and x.dtype in _PAYLOADS and bn.training and x.dim() >= 3 and conv.bias is None):
@@ -194,10 +223,13 @@ def bn_act_conv(x, bn, relu, conv, rowmajor_grad=False):
     if c > FUSED_CONV_MAX_CHANNELS or cout > FUSED_CONV_MAX_CHANNELS or x3.shape[2] % 4 != 0 \
             or x3.shape[0] * x3.shape[2] < (1 << 16):
         return None
-    mean, invstd = _stats(x3, bn)
+    mean, invstd = _stats(x3, bn, in_stats)
     gamma, beta = _affine(bn, c, x.device)
-    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, _f32(conv.weight).view(cout, c), rowmajor_grad)
-    return y.view(x.shape[0], cout, *x.shape[2:])
+    out_stats = stats_partial_buffer(x3, cout, x3.shape[0] * x3.shape[2]) \
+        if want_out_stats and cout <= FUSED_STATS_MAX_CHANNELS and x3.shape[2] % STATS_TILE == 0 else None
+    y = _BnActConv.apply(x3, gamma, beta, mean, invstd, relu, _f32(conv.weight).view(cout, c), rowmajor_grad, out_stats)
+    y = y.view(x.shape[0], cout, *x.shape[2:])
+    return (y, out_stats) if want_out_stats else y
 
 
 def _affine(bn, c, device):
@@ -206,9 +238,9 @@ def _affine(bn, c, device):
     return torch.ones(c, device=device), torch.zeros(c, device=device)
 
 
-def _stats(x3, bn):
+def _stats(x3, bn, partial=None):
     if bn.training or not bn.track_running_stats:
-        return _train_stats(x3, bn)
+        return _train_stats(x3, bn, partial)
     return _f32(bn.running_mean), torch.rsqrt(_f32(bn.running_var) + bn.eps)
 
 
@@ -234,13 +266,13 @@ def _apply_into(x3, bn, relu, mean, invstd, per_sample, out, bstride):
     return out
 
 
-def bn_act(x, bn, relu, rowmajor_grad=False, out=None):
+def bn_act(x, bn, relu, rowmajor_grad=False, out=None, in_stats=None):
     """[relu](bn(x)) for x (B, C, ...) contiguous on the device; ``bn`` is the nn.BatchNormNd module.
     ``out``: write the result into this channel slice of a wider tensor (forward-only callers; see _slice_stride)."""
     x3 = x.contiguous().flatten(2) if x.dim() > 2 else x.contiguous().unsqueeze(-1)
     if not bn.training and torch.is_grad_enabled() and x.requires_grad:
         return None  # eval-mode backward: let the caller take the plain torch path
-    mean, invstd = _stats(x3, bn)
+    mean, invstd = _stats(x3, bn, in_stats)
     bstride = _slice_stride(out, x)
     if bstride is not None and x.dtype in _PAYLOADS and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
         return _apply_into(x3, bn, relu, mean, invstd, False, out, bstride)
@@ -280,11 +312,12 @@ def bn_act_per_sample(x, bn, relu, out=None):
     return y.view(x.shape)
 
 
-def bn_act_maxpool(x, bn, relu):
-    """max over the last axis of [relu](bn(x)) for x (B, C, M, ns) -> (B, C, M)."""
+def bn_act_maxpool(x, bn, relu, in_stats=None):
+    """max over the last axis of [relu](bn(x)) for x (B, C, M, ns) -> (B, C, M).  in_stats: statistics partials of x left by
+    its producer kernel (stats_partial_buffer)."""
     x4 = x.contiguous()
     if x4.shape[-1] > 255 or (not bn.training and torch.is_grad_enabled() and x.requires_grad):
         return None
-    mean, invstd = _stats(x4.flatten(2), bn)
+    mean, invstd = _stats(x4.flatten(2), bn, in_stats)
     gamma, beta = _affine(bn, x4.shape[1], x.device)
     return _BnActMaxPool.apply(x4, gamma, beta, mean, invstd, relu)[0]

@@ -774,3 +774,67 @@ BN_API int mgar_bn_act_maxpool_bwd_strided(const float *dpool, long long sb, lon
     return bn_act_maxpool_bwd_impl<float>(dpool, pooled, arg, x, xarg, B, C, M, nsample, mean, invstd, gamma, relu, workspace, dgamma,
                                           dbeta, dx, stream, sb, sc, sm);
 }
+
+// Merge groups of G consecutive chunk partials (mean, M2) of a channel into one partial each (Chan et al., in double): the
+// output has the same format with chunk' = G * chunk.  grid (ceil(nchunk / G), C), one wave; G = 64 * BN_MERGE_PER_LANE.
+constexpr int BN_MERGE_PER_LANE = 4, BN_MERGE_G = 64 * BN_MERGE_PER_LANE;
+__global__ __launch_bounds__(64) void bn_merge_partials_kernel(const float *__restrict__ in, int nchunk, double n, int chunk,
+                                                              float *__restrict__ out) {
+    const int c = blockIdx.y, g = blockIdx.x, ngroup = gridDim.x;
+    const int i0 = g * BN_MERGE_G, i1 = min(i0 + BN_MERGE_G, nchunk);
+    auto count = [&](int i) { return i + 1 < nchunk ? (double)chunk : n - (double)chunk * (nchunk - 1); };
+    float2 v[BN_MERGE_PER_LANE];
+    double cnt[BN_MERGE_PER_LANE], s = 0.0, tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < BN_MERGE_PER_LANE; ++k) {
+        const int i = i0 + k * 64 + (int)threadIdx.x;
+        const bool ok = i < i1;
+        v[k] = ok ? *reinterpret_cast<const float2 *>(in + ((size_t)c * nchunk + i) * 2) : make_float2(0.f, 0.f);
+        cnt[k] = ok ? count(i) : 0.0;
+        s += cnt[k] * (double)v[k].x;
+        tot += cnt[k];
+    }
+    s = wave_sum_f64(s);
+    tot = wave_sum_f64(tot);
+    const double m = s / tot;
+    double q = 0.0;
+#pragma unroll
+    for (int k = 0; k < BN_MERGE_PER_LANE; ++k) {
+        const double d = (double)v[k].x - m;
+        q += (double)v[k].y + cnt[k] * d * d;
+    }
+    q = wave_sum_f64(q);
+    if (threadIdx.x == 0) *reinterpret_cast<float2 *>(out + ((size_t)c * ngroup + g) * 2) = make_float2((float)m, (float)q);
+}
+
+// BatchNorm training statistics from partials a PRODUCER kernel left behind (mgar_pointwise_conv_fwd_stats,
+// mgar_query_group_proj_stack_fwd_stats): partial (C, nchunk, 2) = per (channel, chunk of `chunk` consecutive elements of the
+// channel in (b, p) order) the chunk's mean and sum of squared deviations; n = B * P elements per channel = nchunk * chunk.
+// Same finalize (Chan merge in double, running statistics) as mgar_bn_train_stats, without its pass over x.
+// workspace: mgar_bn_stats_from_partials_workspace_floats(nchunk, C) floats (many partials are first merged in groups).
+BN_API long long mgar_bn_stats_from_partials_workspace_floats(int nchunk, int C) {
+    if (nchunk < 0 || C < 0) return -1;
+    return nchunk > 4 * BN_MERGE_G ? 2ll * C * ((nchunk + BN_MERGE_G - 1) / BN_MERGE_G) : 0;
+}
+BN_API int mgar_bn_stats_from_partials(const float *partial, int nchunk, int C, long long n, int chunk, float eps, float momentum,
+                                       float *workspace, float *mean, float *invstd, float *running_mean, float *running_var,
+                                       long long *num_batches_tracked, void *stream) {
+    MGAR_REQUIRE(nchunk >= 0 && C >= 0 && n >= 0 && chunk >= 1, "bn_stats_from_partials: bad sizes");
+    if (C == 0 || n == 0) return MGAR_OK;
+    MGAR_REQUIRE(partial && mean && invstd, "bn_stats_from_partials: null pointer");
+    MGAR_REQUIRE((long long)nchunk * chunk >= n && (long long)(nchunk - 1) * chunk < n, "bn_stats_from_partials: nchunk * chunk does not cover n");
+    MGAR_REQUIRE(C <= 65535, "bn_stats_from_partials: C > 65535");
+    if (nchunk > 4 * BN_MERGE_G) {   // one wave per channel would walk them all: merge groups of 256 first (same partial format)
+        MGAR_REQUIRE(workspace, "bn_stats_from_partials: null workspace");
+        MGAR_REQUIRE((long long)chunk * BN_MERGE_G <= 2147483647LL, "bn_stats_from_partials: chunk too large");
+        const int ngroup = (nchunk + BN_MERGE_G - 1) / BN_MERGE_G;
+        hipLaunchKernelGGL(bn_merge_partials_kernel, dim3(ngroup, C), dim3(64), 0, (hipStream_t)stream, partial, nchunk, (double)n, chunk,
+                           workspace);
+        partial = workspace;
+        nchunk = ngroup;
+        chunk *= BN_MERGE_G;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partial, nchunk, C, (double)n, chunk, eps, momentum,
+                       mean, invstd, running_mean, running_var, num_batches_tracked, (float *)nullptr);
+    return check_launch("bn_stats_from_partials: launch failed");
+}

@@ -23,6 +23,8 @@
 //   * W (<= 32 KB) and the per-channel (sc, sh) sit in LDS, read conflict-free as the A operand;
 //   * every wave owns whole 128-column tiles and software-pipelines them: the loads of the next
 //     16-channel slab are in flight while the MFMAs of the current one run.
+#include <type_traits>
+
 #include "common.hpp"
 #include "payload.hpp"
 
@@ -44,9 +46,13 @@ struct PfArgs {
     int B, Cin, Cout, P;
     int w_rs, w_cs;  // W[o, i] = w[o * w_rs + i * w_cs]
     int relu;
+    // optional (P % 128 == 0): per (output channel, 128-column tile) the tile's (mean, M2) of y, in the layout of
+    // bn_partial_kernel with chunk = 128 -- stats[(o * ntiles + tile) * 2 + {0, 1}], tile = b * (P / 128) + tile of the
+    // sample -- so that the BatchNorm that follows needs no pass over y for its statistics (csrc/bn_act.hip, bn_finalize_kernel)
+    float *stats;
 };
 
-template <int OB, typename T>
+template <int OB, typename T, bool STATS = false>
 __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs<T> a) {
     constexpr int PF_KC = PfSlab<OB>::KC, KS = PF_KC / 2;
     constexpr int WLD = OB == 1 ? 32 : 96;  // LDS row stride of W: the two half-waves hit disjoint banks
@@ -127,6 +133,25 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs<T> a) {
             const long long t = wave_id + (s / nkc) * nwaves;
             const int b = (int)(t / tiles_per_b);
             const int p = (int)(t - (long long)b * tiles_per_b) * PF_COLS + 4 * l;
+            if (STATS) {   // the 128 columns of a channel live in the 32 lanes of one half-wave x 4 sub-tiles: exact two-pass
+#pragma unroll
+                for (int ob = 0; ob < OB; ++ob)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v0 = acc[ob][0][r], v1 = acc[ob][1][r], v2 = acc[ob][2][r], v3 = acc[ob][3][r];
+                        float sum = (v0 + v1) + (v2 + v3);
+#pragma unroll
+                        for (int d = 1; d < 32; d <<= 1) sum += __shfl_xor(sum, d, 32);
+                        const float mean = sum * (1.f / PF_COLS);
+                        const float d0 = v0 - mean, d1 = v1 - mean, d2 = v2 - mean, d3 = v3 - mean;
+                        float m2 = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+                        for (int d = 1; d < 32; d <<= 1) m2 += __shfl_xor(m2, d, 32);
+                        const int o = ob * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (l == 0 && o < a.Cout)
+                            *reinterpret_cast<float2 *>(a.stats + ((size_t)o * ntiles + t) * 2) = make_float2(mean, m2);
+                    }
+            }
 #pragma unroll
             for (int ob = 0; ob < OB; ++ob)
 #pragma unroll
@@ -152,20 +177,20 @@ __global__ __launch_bounds__(256, 2) void pointwise_fwd_kernel(PfArgs<T> a) {
     }
 }
 
-template <int OB, typename T>
+template <int OB, typename T, bool STATS = false>
 static void launch_pf(const PfArgs<T> &a, hipStream_t st) {
     constexpr int WLD = OB == 1 ? 32 : 96, PF_KC = PfSlab<OB>::KC;
     const int nkc = (a.Cin + PF_KC - 1) / PF_KC;
     const int lds = nkc * PF_KC * (WLD + 4) * (int)sizeof(float);
     static int attr_lds = 0;
     if (lds > 65536 && lds > attr_lds) {
-        (void)hipFuncSetAttribute((const void *)pointwise_fwd_kernel<OB, T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void *)pointwise_fwd_kernel<OB, T, STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_lds = lds;
     }
     const long long ntiles = (long long)a.B * ((a.P + PF_COLS - 1) / PF_COLS);
     long long wgs = (ntiles + 3) / 4;
     if (wgs > 2048) wgs = 2048;   // 8 workgroups per CU; waves stride over the tiles
-    hipLaunchKernelGGL((pointwise_fwd_kernel<OB, T>), dim3((unsigned)wgs), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((pointwise_fwd_kernel<OB, T, STATS>), dim3((unsigned)wgs), dim3(256), lds, st, a);
 }
 
 }  // namespace mgar
@@ -175,7 +200,7 @@ using namespace mgar;
 template <typename T>
 static int pointwise_conv_fwd_impl(const T *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride, int Cout,
                                    const float *in_mean, const float *in_invstd, const float *in_gamma, const float *in_beta,
-                                   int in_relu, T *y, void *stream) {
+                                   int in_relu, T *y, void *stream, float *out_stats = nullptr) {
     MGAR_REQUIRE(B >= 0 && Cin >= 0 && Cout >= 0 && P >= 0, "pointwise_conv_fwd: negative size");
     if ((long long)B * P == 0 || Cout == 0) return MGAR_OK;
     MGAR_REQUIRE(x && w && y, "pointwise_conv_fwd: null pointer");
@@ -184,10 +209,13 @@ static int pointwise_conv_fwd_impl(const T *x, int B, int Cin, int P, const floa
         set_error("pointwise_conv_fwd: needs 1 <= Cin <= 256, Cout <= 64 and P % 4 == 0 (use the library GEMM otherwise)");
         return MGAR_EUNSUPPORTED;
     }
-    PfArgs<T> a{x, w, in_mean, in_invstd, in_gamma, in_beta, y, B, Cin, Cout, P, w_row_stride, w_col_stride, in_relu};
+    MGAR_REQUIRE(out_stats == nullptr || P % PF_COLS == 0, "pointwise_conv_fwd: output statistics need P % 128 == 0");
+    PfArgs<T> a{x, w, in_mean, in_invstd, in_gamma, in_beta, y, B, Cin, Cout, P, w_row_stride, w_col_stride, in_relu, out_stats};
     hipStream_t st = (hipStream_t)stream;
     KtScope kt(KT_POINTWISE_FWD, st, (double)sizeof(T) * B * P * (Cin + Cout), 2.0 * (double)B * P * Cin * Cout);
-    if (Cout <= 32) launch_pf<1, T>(a, st);
+    if (out_stats) {   // Cout <= 32 (checked by the entry point): the 64-channel instance has no registers left for it
+        if constexpr (std::is_same<T, float>::value) launch_pf<1, float, true>(a, st);
+    } else if (Cout <= 32) launch_pf<1, T>(a, st);
     else launch_pf<2, T>(a, st);
     return check_launch("pointwise_conv_fwd: launch failed");
 }
@@ -205,4 +233,19 @@ PF_API int mgar_pointwise_conv_fwd_bf16(const void *x, int B, int Cin, int P, co
                                         const float *in_beta, int in_relu, void *y, void *stream) {
     return pointwise_conv_fwd_impl<bf16_t>((const bf16_t *)x, B, Cin, P, w, w_row_stride, w_col_stride, Cout, in_mean, in_invstd,
                                            in_gamma, in_beta, in_relu, (bf16_t *)y, stream);
+}
+
+// pointwise_conv_fwd that also leaves the BatchNorm statistics partials of its OUTPUT: out_stats (Cout, B * P / 128, 2) floats =
+// per (channel, 128-column tile) the tile's mean and sum of squared deviations, the chunk format mgar_bn_stats_from_partials
+// finalizes (chunk = 128).  P % 128 == 0, Cout <= 32.  fp32.  Saves the BatchNorm's own pass over y (4 * B * Cout * P bytes).
+PF_API int mgar_pointwise_conv_fwd_stats(const float *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride,
+                                         int Cout, const float *in_mean, const float *in_invstd, const float *in_gamma,
+                                         const float *in_beta, int in_relu, float *y, float *out_stats, void *stream) {
+    MGAR_REQUIRE(out_stats, "pointwise_conv_fwd_stats: null pointer");
+    if (Cout > 32) {
+        set_error("pointwise_conv_fwd_stats: Cout <= 32 (run mgar_pointwise_conv_fwd and the BatchNorm's own statistics pass)");
+        return MGAR_EUNSUPPORTED;
+    }
+    return pointwise_conv_fwd_impl<float>(x, B, Cin, P, w, w_row_stride, w_col_stride, Cout, in_mean, in_invstd, in_gamma, in_beta,
+                                          in_relu, y, stream, out_stats);
 }

@@ -154,8 +154,10 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
                                                            const int *__restrict__ new_xyz_batch_cnt,
                                                            const T *__restrict__ features, int ld,
                                                            const float *__restrict__ wx, const int *__restrict__ idx,
-                                                           T *__restrict__ rel_out, T *__restrict__ y_out) {
+                                                           T *__restrict__ rel_out, T *__restrict__ y_out,
+                                                           float *__restrict__ stats) {
     __shared__ QsTile t;
+    __shared__ float red[8][QS_CH];
     int col0;
     const int ncol = qs_prologue(t, B, M, nsample, idx, new_xyz_batch_cnt, xyz_batch_cnt, col0);
     const size_t ms = (size_t)M * nsample;
@@ -189,6 +191,36 @@ __global__ __launch_bounds__(256) void qg_stack_fwd_kernel(int B, int M, int C, 
         for (int e = threadIdx.x; e < nch * QS_COLS; e += 256) {     // lanes along the columns
             const int ci = e / QS_COLS, cl = e - ci * QS_COLS;
             if (cl < ncol) Payload<T>::st(y_out + (size_t)(c0 + ci) * ms + col0 + cl, t.tile[cl][ci]);
+        }
+        if (stats) {
+            // BatchNorm statistics partials of y for the layer that follows: per channel the (mean, M2) of this tile's 128
+            // columns (total % 128 == 0), exact two-pass over the LDS tile; thread = (channel ci, segment of 16 columns).
+            // Layout: stats[(channel * ntiles + tile) * 2 + {0, 1}] = the chunk format of bn_finalize_kernel, chunk = 128.
+            const int ci = threadIdx.x & (QS_CH - 1), seg = threadIdx.x / QS_CH;
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < QS_COLS / 8; ++j) sum += t.tile[seg * (QS_COLS / 8) + j][ci];
+            red[seg][ci] = sum;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tot += red[k][ci];
+            const float mean = tot * (1.f / QS_COLS);
+            float m2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < QS_COLS / 8; ++j) {
+                const float d = t.tile[seg * (QS_COLS / 8) + j][ci] - mean;
+                m2 += d * d;
+            }
+            __syncthreads();
+            red[seg][ci] = m2;
+            __syncthreads();
+            if (seg == 0 && ci < nch) {
+                float q = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) q += red[k][ci];
+                *reinterpret_cast<float2 *>(stats + ((size_t)(c0 + ci) * gridDim.x + blockIdx.x) * 2) = make_float2(mean, q);
+            }
         }
         __syncthreads();
     }
@@ -954,15 +986,16 @@ QG_API int mgar_query_group_proj_batch_bwd(int b, int c, int n, int npoints, int
 template <typename T>
 static int qg_stack_fwd(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt, const float *new_xyz,
                         const int *new_xyz_batch_cnt, const T *features, int ld, const float *wx, const int *idx,
-                        T *rel_out, T *y_out, void *stream, const char *what) {
+                        T *rel_out, T *y_out, void *stream, const char *what, float *out_stats = nullptr) {
     MGAR_REQUIRE(B >= 0 && M >= 0 && C >= 0 && nsample >= 0, "query_group (stack) fwd: negative size");
     const long long total = (long long)M * nsample;
     if (B == 0 || total == 0) return MGAR_OK;
     MGAR_REQUIRE(xyz && xyz_batch_cnt && new_xyz && new_xyz_batch_cnt && idx && (features || C == 0) && (y_out || C == 0) &&
                      (rel_out || y_out), "query_group (stack) fwd: null pointer");
+    MGAR_REQUIRE(out_stats == nullptr || total % QS_COLS == 0, "query_group (stack) fwd: output statistics need M * nsample % 128 == 0");
     KtScope kt(KT_QUERY_GROUP_FWD, (hipStream_t)stream, (double)total * (4.0 + (double)sizeof(T) * (C + 3)));
     hipLaunchKernelGGL(qg_stack_fwd_kernel<T>, dim3(ceil_div(total, QS_COLS)), dim3(256), 0, (hipStream_t)stream, B, M, C, nsample,
-                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, ld, wx, idx, rel_out, y_out);
+                       xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, ld, wx, idx, rel_out, y_out, out_stats);
     return check_launch(what);
 }
 
@@ -998,6 +1031,18 @@ QG_API int mgar_query_group_proj_stack_fwd(int B, int M, int C, int nsample, con
     MGAR_REQUIRE(wx && zf && y_out && zf_ld >= C, "query_group_proj_stack_fwd: null pointer or zf_ld < C");
     return qg_stack_fwd<float>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, zf_ld, wx, idx, rel_out, y_out,
                                stream, "query_group_proj_stack_fwd: launch failed");
+}
+
+// The same, also leaving the BatchNorm statistics partials of y_out: out_stats (C, M * nsample / 128, 2) floats = per (channel,
+// 128-column tile) the tile's mean and sum of squared deviations (chunk format of mgar_bn_stats_from_partials, chunk = 128).
+// M * nsample % 128 == 0.  fp32.
+QG_API int mgar_query_group_proj_stack_fwd_stats(int B, int M, int C, int nsample, const float *xyz, const int *xyz_batch_cnt,
+                                                 const float *new_xyz, const int *new_xyz_batch_cnt, const float *zf, int zf_ld,
+                                                 const float *wx, const int *idx, float *rel_out, float *y_out, float *out_stats,
+                                                 void *stream) {
+    MGAR_REQUIRE(wx && zf && y_out && out_stats && zf_ld >= C, "query_group_proj_stack_fwd_stats: null pointer or zf_ld < C");
+    return qg_stack_fwd<float>(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, zf_ld, wx, idx, rel_out, y_out,
+                               stream, "query_group_proj_stack_fwd_stats: launch failed", out_stats);
 }
 
 QG_API int mgar_query_group_proj_stack_bwd(int B, int M, int C, int nsample, const float *grad_y, const int *idx,

@@ -82,17 +82,19 @@ class PointwiseSequential(nn.Sequential):
 
     fuse_bn_conv = True
 
-    def _run(self, x, pool_last, start=0, rowmajor_input_grad=False):
+    def _run(self, x, pool_last, start=0, rowmajor_input_grad=False, input_stats=None):
         from . import bn_ops
         layers = list(self)
         i, n = start, len(layers)
         pooled = False
+        stats = input_stats          # BatchNorm statistics partials of the current x, if its producer kernel left them
         while i < n:
             layer = layers[i]
             # only the layer that consumes the input can hand its gradient back row-major
             rm = rowmajor_input_grad and i == start and x.dim() == 4 and x.shape[0] == 1
             if _is_pointwise(layer):
                 x = conv1x1(layer, x)
+                stats = None
                 i += 1
             elif isinstance(layer, _BN_TYPES) and x.is_cuda:
                 relu = i + 1 < n and isinstance(layers[i + 1], nn.ReLU)
@@ -100,34 +102,37 @@ class PointwiseSequential(nn.Sequential):
                 y = None
                 nxt = i + (2 if relu else 1)
                 if nxt < n and _is_pointwise(layers[nxt]) and self.fuse_bn_conv:
-                    # [BN -> ReLU -> next conv] in one pass; the activated tensor is never written
-                    y = bn_ops.bn_act_conv(x, layer, relu, layers[nxt], rowmajor_grad=rm)
+                    # [BN -> ReLU -> next conv] in one pass; the activated tensor is never written.  If a BatchNorm follows that
+                    # conv, the kernel also leaves the statistics partials of its output (no statistics pass over it)
+                    feeds_bn = nxt + 1 < n and isinstance(layers[nxt + 1], _BN_TYPES) and layers[nxt + 1].training
+                    y = bn_ops.bn_act_conv(x, layer, relu, layers[nxt], rowmajor_grad=rm, in_stats=stats, want_out_stats=feeds_bn)
                     if y is not None:
-                        x = y
+                        x, stats = y if feeds_bn else (y, None)
                         i = nxt + 1
                         continue
                 if pool_last and last and x.dim() == 4:
-                    y = bn_ops.bn_act_maxpool(x, layer, relu)
+                    y = bn_ops.bn_act_maxpool(x, layer, relu, in_stats=stats)
                     pooled = y is not None
                 if y is None:
-                    y = bn_ops.bn_act(x, layer, relu, rowmajor_grad=rm)
+                    y = bn_ops.bn_act(x, layer, relu, rowmajor_grad=rm, in_stats=stats)
                 if y is None:            # eval-mode backward etc.: plain torch
                     y = layer(x)
                     relu = False
-                x = y
+                x, stats = y, None
                 i += 2 if relu else 1
             else:
                 x = layer(x)
+                stats = None
                 i += 1
         return x, pooled
 
     def forward(self, x):
         return self._run(x, False)[0]
 
-    def forward_maxpool(self, x, start=0, rowmajor_input_grad=False):
+    def forward_maxpool(self, x, start=0, rowmajor_input_grad=False, input_stats=None):
         """(B, C, M, ns) -> (B, C', M): the MLP (from layer `start`) followed by a max over ns.
         ``rowmajor_input_grad``: the caller's backward prefers d x as (M * ns, C) rows (B = 1; see bn_ops._bwd_rowmajor)."""
-        y, pooled = self._run(x, True, start, rowmajor_input_grad)
+        y, pooled = self._run(x, True, start, rowmajor_input_grad, input_stats)
         return y if pooled else y.max(dim=3).values
 
     def first_layer_foldable(self, c_in):

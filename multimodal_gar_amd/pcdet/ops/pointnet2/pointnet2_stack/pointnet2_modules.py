@@ -91,11 +91,14 @@ class StackSAModuleMSG(nn.Module):
                     xyz, xyz_batch_cnt.int(), new_xyz, new_xyz_batch_cnt.int(), features,
                     tuple(self.groupers[k].radius for k in fold), tuple(self.groupers[k].nsample for k in fold),
                     tuple(self._rows_bwd(k) for k in fold), *[self.mlps[k][0].weight for k in fold])
-                projected = dict(zip(fold, ys))
+                projected = dict(zip(fold, ys[:len(fold)]))
+                proj_stats = dict(zip(fold, ys[len(fold):]))
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if k in projected:
                 y0 = projected[k]
-                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1, rowmajor_input_grad=self._rows_bwd(k))
+                st = proj_stats[k] if proj_stats[k].numel() else None
+                x = mlp.forward_maxpool(y0.view(1, y0.shape[0], new_xyz.shape[0], -1), start=1, rowmajor_input_grad=self._rows_bwd(k),
+                                        input_stats=st)
                 per_scale.append(x.squeeze(0).permute(1, 0))
                 continue
             assert features is None or features.dim() == 2, "channel-major features need the projected (foldable) path"

@@ -105,11 +105,17 @@ def query_group_grad_wrapper(B, M, C, nsample, grad_out, idx_raw, new_xyz_batch_
 
 
 def query_group_proj_wrapper(B, M, C, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, zf, wx, idx_raw, rel_out, y_out,
-                             zf_ld=None, zf_col=0):
-    """zf: (N, zf_ld) matrix whose columns zf_col .. zf_col + C hold this scale's projection."""
+                             zf_ld=None, zf_col=0, out_stats=None):
+    """zf: (N, zf_ld) matrix whose columns zf_col .. zf_col + C hold this scale's projection.
+    out_stats (C, M * nsample / 128, 2) fp32: also leave the BatchNorm statistics partials of y_out (bn_ops.StatsPartial)."""
     zf_ld = C if zf_ld is None else zf_ld
     dt = zf.dtype
     L.pptr(zf, dt)             # device / contiguity / dtype checks; the call below takes the pointer of the column block
+    if out_stats is not None:
+        L.call("mgar_query_group_proj_stack_fwd_stats", B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
+               L.iptr(new_xyz_batch_cnt), zf.data_ptr() + zf.element_size() * zf_col, zf_ld, L.fptr(wx), L.iptr(idx_raw),
+               L.fptr(rel_out) if rel_out is not None else None, L.fptr(y_out), L.fptr(out_stats), L.stream_of(xyz))
+        return 1
     L.payload_call("mgar_query_group_proj_stack_fwd", dt, B, M, C, nsample, L.fptr(xyz), L.iptr(xyz_batch_cnt), L.fptr(new_xyz),
                    L.iptr(new_xyz_batch_cnt), zf.data_ptr() + zf.element_size() * zf_col, zf_ld, L.fptr(wx), L.iptr(idx_raw),
                    L.pptr(rel_out, dt) if rel_out is not None else None, L.pptr(y_out, dt), L.stream_of(xyz))

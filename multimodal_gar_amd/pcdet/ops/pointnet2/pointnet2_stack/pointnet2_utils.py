@@ -165,7 +165,9 @@ class _FusedQueryGroupProjMSG(Function):
     d W_f = grad_zf^T features runs on csrc/rowmajor_dw.hip.
 
     apply(xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt, features, radii, nsamples, rows_bwd, *weights)
-    with weights[k] (C_k, 3 + C) -> (y_1, ..., y_K), y_k (C_k, M * nsample_k) channel-major.
+    with weights[k] (C_k, 3 + C) -> (y_1, ..., y_K, s_1, ..., s_K), y_k (C_k, M * nsample_k) channel-major, s_k the BatchNorm
+    statistics partials of y_k left by the grouping kernel (bn_ops.stats_partial_buffer; an empty tensor where that does not
+    apply), so that the BatchNorm after the folded layer needs no pass over y_k.
     rows_bwd[k]: the consumer of y_k hands its gradient back as rows (M * nsample_k, C_k) (nn_utils.forward_maxpool(
     rowmajor_input_grad=True)); scale k then takes the atomic-free, bit-reproducible backward (qg_stack_bwd_rows_kernel),
     which also forms d wx_k from the coordinates: the forward stores no relative coordinates for it."""
@@ -198,23 +200,29 @@ class _FusedQueryGroupProjMSG(Function):
         for radius, nsample, idx in zip(radii, nsamples, idxs):
             pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
         rows_bwd = tuple(bool(r) and c <= 64 and zf.dtype == torch.float32 for r, c in zip(rows_bwd, chans))
+        from .....bn_ops import stats_partial_buffer
+        stats = []
         for radius, nsample, w, c, idx, rows in zip(radii, nsamples, ws, chans, idxs, rows_bwd):
             wx = w[:, :3].contiguous().float()
             rel = _empty(xyz, (3, n_query * nsample), zf.dtype) if need_bwd and not rows else None
             y = _empty(xyz, (c, n_query * nsample), zf.dtype)
+            st = stats_partial_buffer(y, c, n_query * nsample)        # None off the device / for bf16 payloads / odd sizes
             pointnet2.query_group_proj_wrapper(n_samples, n_query, c, nsample, xyz, xyz_batch_cnt, new_xyz, new_xyz_batch_cnt,
-                                               zf, wx, idx, rel, y, zf_ld=ld, zf_col=col)
+                                               zf, wx, idx, rel, y, zf_ld=ld, zf_col=col, **({"out_stats": st} if st is not None else {}))
+            stats.append(st if st is not None else y.new_empty((0,)))
             outs.append(y)
             saved += [idx, rel if rel is not None else idx]
             col += c
         ctx.save_for_backward(xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, xyz, new_xyz, *saved)
         ctx.meta = (n_samples, n_query, tuple(chans), tuple(nsamples), tuple(w.shape for w in weights), rows_bwd)
-        return tuple(outs)
+        ctx.mark_non_differentiable(*stats)
+        return tuple(outs) + tuple(stats)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, *grad_ys):
+    def backward(ctx, *grads):
         from .....nn_utils import pointwise_dw
+        grad_ys = grads[:len(grads) // 2]
         xyz_batch_cnt, new_xyz_batch_cnt, features, w_f, xyz, new_xyz = ctx.saved_tensors[:6]
         saved = ctx.saved_tensors[6:]
         n_samples, n_query, chans, nsamples, w_shapes, rows_bwd = ctx.meta
