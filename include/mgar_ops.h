@@ -320,6 +320,14 @@ int mgar_bn_act_fwd_grouped(const float *x, int G, int C, int P, const float *me
                             const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *y, void *stream);
+/* Training statistics + apply [+ ReLU] in ONE launch for small channels: at most 16 384 elements per channel (B * P, or P with
+ * per_sample statistics) and P % 4 == 0, MGAR_EUNSUPPORTED otherwise.  What mgar_bn_train_stats[_grouped] followed by
+ * mgar_bn_act_fwd_into computes (forward only; the launch-bound one-clip step has ~45 such BatchNorms in the I3D).
+ * mean / invstd: optional outputs (C, or B * C with per_sample); workspace: B * C floats, needed with per_sample + running
+ * statistics; y_bstride < 0: y contiguous. */
+int mgar_bn_act_small(const float *x, int B, int C, int P, int per_sample, float eps, float momentum, const float *gamma,
+                      const float *beta, int relu, float *workspace, float *mean, float *invstd, float *running_mean,
+                      float *running_var, long long *num_batches_tracked, float *y, long long y_bstride, void *stream);
 /* bn_act_fwd (stats_per_sample = 0) / bn_act_fwd_grouped (1) with y a CHANNEL SLICE of a wider (B, C_total, P) tensor:
  * consecutive samples of y are y_bstride >= C * P elements apart.  The branches of an Inception module (reference
  * model/backbone.py:227-260: torch.cat of four branch outputs) write straight into the concatenated tensor. */
@@ -567,6 +575,9 @@ int mgar_bn_act_fwd_bf16(const void *x, int B, int C, int P, const float *mean, 
                          const float *gamma, const float *beta, int relu, void *y, void *stream);
 int mgar_three_interpolate_batch_into_bf16(int b, int c, int m, int n, const void *points, const int *idx, const float *weight,
                                            void *out, long long out_bstride, void *stream);
+int mgar_bn_act_small_bf16(const void *x, int B, int C, int P, int per_sample, float eps, float momentum, const float *gamma,
+                           const float *beta, int relu, float *workspace, float *mean, float *invstd, float *running_mean,
+                           float *running_var, long long *num_batches_tracked, void *y, long long y_bstride, void *stream);
 int mgar_bn_act_fwd_into_bf16(const void *x, int B, int C, int P, const float *mean, const float *invstd, const float *gamma,
                               const float *beta, int relu, int stats_per_sample, void *y, long long y_bstride, void *stream);
 int mgar_bn_act_fwd_grouped_bf16(const void *x, int G, int C, int P, const float *mean, const float *invstd,

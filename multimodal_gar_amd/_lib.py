@@ -75,6 +75,7 @@ _PROTOS = {
     "mgar_pointwise_conv_fwd_stats": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "mgar_query_group_proj_stack_fwd_stats": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "mgar_bn_act_maxpool_bwd_strided": [_P, _LL, _LL, _LL, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_act_small": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P],
     "mgar_bn_act_fwd_into": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _LL, _P],
     "mgar_bn_act_bwd_rowmajor": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_query_group_stack_inverse_items": [_I, _I, _LL],
@@ -113,7 +114,7 @@ _PROTOS = {
 # bf16-payload twins (include/mgar_ops.h, last section): identical argument lists
 for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_query_group_proj_batch_fwd",
            "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
-           "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
+           "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_small", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
            "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_batch_into", "mgar_three_interpolate_stack",
            "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]

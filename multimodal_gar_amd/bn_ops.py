@@ -257,6 +257,32 @@ def _slice_stride(out, x):
     return out.stride(0) if out.stride(0) >= inner else None
 
 
+SMALL_CHANNEL_MAX = 16384   # csrc/bn_act.hip, bn_small_fused_kernel: elements per channel one workgroup keeps in registers
+
+
+def _small_fused(x, x3, bn, relu, per_sample, out):
+    """Statistics + apply in one launch for small channels (forward only), or None if the shapes do not qualify."""
+    b, c, p = x3.shape
+    if (p if per_sample else b * p) > SMALL_CHANNEL_MAX or p % 4 != 0 or x3.dtype not in _PAYLOADS:
+        return None
+    bstride = _slice_stride(out, x)
+    y = out if bstride is not None else torch.empty_like(x)
+    track = bn.track_running_stats and bn.running_mean is not None
+    rows = b * c if per_sample else c
+    need = per_sample and track
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device) if need else None
+    ws = torch.empty((rows,), dtype=torch.float32, device=x.device) if need else None
+    gamma, beta = _affine(bn, c, x.device)
+    dt = x3.dtype
+    L.payload_call("mgar_bn_act_small", dt, L.pptr(x3, dt), b, c, p, int(per_sample), float(bn.eps),
+                   float(bn.momentum if bn.momentum is not None else 0.1), L.fptr(gamma), L.fptr(beta), int(relu),
+                   L.fptr(ws) if ws is not None else None, L.fptr(mean) if mean is not None else None, None,
+                   L.fptr(bn.running_mean) if track else None, L.fptr(bn.running_var) if track else None,
+                   L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
+                   y.data_ptr(), bstride if bstride is not None else -1, L.stream_of(x3))
+    return y
+
+
 def _apply_into(x3, bn, relu, mean, invstd, per_sample, out, bstride):
     b, c, p = x3.shape
     gamma, beta = _affine(bn, c, x3.device)
@@ -272,6 +298,11 @@ def bn_act(x, bn, relu, rowmajor_grad=False, out=None, in_stats=None):
     x3 = x.contiguous().flatten(2) if x.dim() > 2 else x.contiguous().unsqueeze(-1)
     if not bn.training and torch.is_grad_enabled() and x.requires_grad:
         return None  # eval-mode backward: let the caller take the plain torch path
+    forward_only = not (torch.is_grad_enabled() and (x.requires_grad or (bn.affine and bn.weight.requires_grad)))
+    if forward_only and bn.training and x.is_cuda and in_stats is None:
+        y = _small_fused(x, x3, bn, relu, False, out)
+        if y is not None:
+            return y
     mean, invstd = _stats(x3, bn, in_stats)
     bstride = _slice_stride(out, x)
     if bstride is not None and x.dtype in _PAYLOADS and not (torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad)):
@@ -291,6 +322,9 @@ def bn_act_per_sample(x, bn, relu, out=None):
     g, c, p = x3.shape
     if g * c > 65535:
         return None
+    y = _small_fused(x, x3, bn, relu, True, out)
+    if y is not None:
+        return y
     mean = torch.empty((g * c,), dtype=torch.float32, device=x.device)
     invstd = torch.empty_like(mean)
     track = bn.track_running_stats and bn.running_mean is not None

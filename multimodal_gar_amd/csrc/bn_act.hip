@@ -125,6 +125,82 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict
     if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
 }
 
+// ---- small channels: statistics + apply in ONE launch (round 2) ---------------------------------------------------------
+// When a whole channel (n = B * P <= BN_SMALL_MAX elements) fits the registers of one workgroup, the three launches
+// (partial, finalize, apply) collapse into one: read x once (up to 16 float4 per thread), exact two-pass mean / M2 in
+// registers, running statistics, apply, write y.  At one clip per rank ~45 of the I3D's BatchNorms are this small and the
+// step is launch-bound (profiles/README.md, round 2).  P % 4 == 0.  grid (rows): rows = C, or G * C with per-sample
+// statistics (then B = 1 per row).  y may be a channel slice of a wider tensor (y_bstride, as bn_apply_kernel).
+constexpr int BN_SMALL_V = 16, BN_SMALL_MAX = BN_THREADS * 4 * BN_SMALL_V;   // 16 384 elements per channel
+template <bool RELU, typename T>
+__global__ __launch_bounds__(BN_THREADS) void bn_small_fused_kernel(const T *__restrict__ x, int B, int C, int P, int per_sample,
+                                                                    float eps, float momentum, const float *__restrict__ gamma,
+                                                                    const float *__restrict__ beta, float *__restrict__ mean_out,
+                                                                    float *__restrict__ invstd_out, float *__restrict__ var_out,
+                                                                    float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                                    long long *__restrict__ num_batches_tracked, T *__restrict__ y,
+                                                                    long long y_bstride) {
+    __shared__ float scratch[BN_THREADS / 64];
+    const int row = blockIdx.x;                          // per_sample: row = g * C + c, its P elements are contiguous
+    const int c = per_sample ? row % C : row;
+    const int nb = per_sample ? 1 : B;
+    const long long n = (long long)nb * P;
+    float4 v[BN_SMALL_V];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_V; ++u) {
+        const long long e = ((long long)u * BN_THREADS + threadIdx.x) * 4;
+        if (e < n) {
+            const size_t o = per_sample ? (size_t)row * P + e : chan_off(e, c, C, P);
+            v[u] = Payload<T>::ld4(x + o);
+            s += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        } else {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mu = block_sum(s, scratch) / (float)n;
+    float q = 0.f;
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_V; ++u) {
+        const long long e = ((long long)u * BN_THREADS + threadIdx.x) * 4;
+        if (e < n) {
+            const float dx = v[u].x - mu, dy = v[u].y - mu, dz = v[u].z - mu, dw = v[u].w - mu;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+    }
+    __syncthreads();                                     // block_sum reuses its scratch
+    const float var = fmaxf(block_sum(q, scratch) / (float)n, 0.f);
+    const float is = (float)(1.0 / sqrt((double)var + (double)eps));
+    if (threadIdx.x == 0) {
+        if (mean_out) mean_out[row] = mu;
+        if (invstd_out) invstd_out[row] = is;
+        if (var_out) var_out[row] = var;                 // per-sample statistics: the running update walks the samples in order
+        if (!per_sample) {
+            if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+            if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1 ? var * (float)n / (float)(n - 1) : var);
+            if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+        }
+    }
+    const float sc = is * (gamma ? gamma[c] : 1.f), sh = beta ? beta[c] : 0.f;
+#pragma unroll
+    for (int u = 0; u < BN_SMALL_V; ++u) {
+        const long long e = ((long long)u * BN_THREADS + threadIdx.x) * 4;
+        if (e < n) {
+            float4 r = v[u];
+            r.x = (r.x - mu) * sc + sh; r.y = (r.y - mu) * sc + sh; r.z = (r.z - mu) * sc + sh; r.w = (r.w - mu) * sc + sh;
+            if (RELU) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
+            size_t o;
+            if (per_sample) {
+                o = (size_t)(row / C) * y_bstride + (size_t)c * P + e;
+            } else {
+                const long long b = e / P;
+                o = (size_t)b * y_bstride + (size_t)c * P + (size_t)(e - b * P);
+            }
+            Payload<T>::st4(y + o, r);
+        }
+    }
+}
+
 // ---- apply: 4 B read + 4 B written per element ----------------------------------------------
 // grid (B*C rows, ceil(P / (256*4*BN_APPLY_V)))
 constexpr int BN_APPLY_V = 4;  // float4 per thread
@@ -701,6 +777,45 @@ BN_BOTH(mgar_bn_act_fwd_grouped,
          int relu, void *y, void *stream),
         bn_act_fwd_impl<float>(x, G, C, P, mean, invstd, gamma, beta, relu, y, 1, stream),
         bn_act_fwd_impl<bf16_t>((cbf)x, G, C, P, mean, invstd, gamma, beta, relu, (mbf)y, 1, stream))
+// Statistics + apply in one launch for small channels (B * P, or P with per-sample statistics, <= 16 384; P % 4 == 0): what
+// mgar_bn_train_stats[_grouped] followed by mgar_bn_act_fwd_into computes, forward only.  mean / invstd (rows) optional
+// outputs; workspace: rows floats (per-sample statistics only: the biased variances for the running update).
+template <typename T>
+static int bn_act_small_impl(const T *x, int B, int C, int P, int per_sample, float eps, float momentum, const float *gamma,
+                             const float *beta, int relu, float *workspace, float *mean, float *invstd, float *running_mean,
+                             float *running_var, long long *num_batches_tracked, T *y, long long y_bstride, void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_small: bad sizes");
+    if ((long long)B * C * P == 0) return MGAR_OK;
+    const long long n = per_sample ? P : (long long)B * P;
+    if (n > BN_SMALL_MAX || (P & 3) != 0) {
+        set_error("bn_act_small: needs at most 16384 elements per channel and P % 4 == 0");
+        return MGAR_EUNSUPPORTED;
+    }
+    MGAR_REQUIRE(x && y, "bn_act_small: null pointer");
+    if (y_bstride < 0) y_bstride = (long long)C * P;
+    MGAR_REQUIRE(y_bstride >= (long long)C * P && (y_bstride * (long long)sizeof(T)) % 16 == 0 && (uintptr_t)y % 16 == 0,
+                 "bn_act_small: bad output slice");
+    const int rows = per_sample ? B * C : C;
+    const bool track = running_mean || running_var || num_batches_tracked;
+    MGAR_REQUIRE(!(per_sample && track) || (workspace && mean), "bn_act_small: per-sample running update needs workspace and mean");
+    hipStream_t st = (hipStream_t)stream;
+    float *var = per_sample && track ? workspace : nullptr;
+    if (relu) hipLaunchKernelGGL((bn_small_fused_kernel<true, T>), dim3(rows), dim3(BN_THREADS), 0, st, x, B, C, P, per_sample, eps, momentum, gamma, beta, mean, invstd, var, running_mean, running_var, num_batches_tracked, y, y_bstride);
+    else hipLaunchKernelGGL((bn_small_fused_kernel<false, T>), dim3(rows), dim3(BN_THREADS), 0, st, x, B, C, P, per_sample, eps, momentum, gamma, beta, mean, invstd, var, running_mean, running_var, num_batches_tracked, y, y_bstride);
+    if (per_sample && track)
+        hipLaunchKernelGGL(bn_running_update_grouped_kernel, dim3(ceil_div(C, 64)), dim3(64), 0, st, mean, var, B, C, (double)P, momentum,
+                           running_mean, running_var, num_batches_tracked);
+    return check_launch("bn_act_small: launch failed");
+}
+BN_BOTH(mgar_bn_act_small,
+        (const float *x, int B, int C, int P, int per_sample, float eps, float momentum, const float *gamma, const float *beta, int relu,
+         float *workspace, float *mean, float *invstd, float *running_mean, float *running_var, long long *num_batches_tracked,
+         float *y, long long y_bstride, void *stream),
+        (const void *x, int B, int C, int P, int per_sample, float eps, float momentum, const float *gamma, const float *beta, int relu,
+         float *workspace, float *mean, float *invstd, float *running_mean, float *running_var, long long *num_batches_tracked,
+         void *y, long long y_bstride, void *stream),
+        bn_act_small_impl<float>(x, B, C, P, per_sample, eps, momentum, gamma, beta, relu, workspace, mean, invstd, running_mean, running_var, num_batches_tracked, y, y_bstride, stream),
+        bn_act_small_impl<bf16_t>((cbf)x, B, C, P, per_sample, eps, momentum, gamma, beta, relu, workspace, mean, invstd, running_mean, running_var, num_batches_tracked, (mbf)y, y_bstride, stream))
 // the same with y a CHANNEL SLICE of a wider (B, C_total, P) tensor: sample b of the result starts y_bstride elements after
 // sample b - 1 (an Inception module's branches write straight into the concatenated output: no torch.cat pass)
 BN_BOTH(mgar_bn_act_fwd_into,

@@ -118,3 +118,37 @@ def test_three_interpolate_concat_equals_interpolate_then_cat(dtype):
             (y * torch.linspace(-1, 1, y.numel(), device="cuda").view(y.shape)).sum().backward()
             res.append((k.grad, s.grad))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("per_sample", [False, True])
+@pytest.mark.parametrize("shape", [(3, 24, 2, 23, 40), (1, 64, 4, 44, 80), (2, 8, 1, 1, 4)])
+def test_small_channel_batchnorm_in_one_launch_equals_three_launches(dtype, per_sample, shape, monkeypatch):
+    """bn_small_fused_kernel (statistics + apply in one launch, <= 16 384 elements per channel) against the partial / finalize /
+    apply path: outputs, running statistics, writing into a channel slice; also with a large common mean."""
+    from multimodal_gar_amd import bn_ops
+    torch.manual_seed(7)
+    c = shape[1]
+
+    def make():
+        bn = torch.nn.BatchNorm3d(c, eps=1e-3, momentum=0.01).cuda().train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_()
+        return bn
+    x = (torch.randn(*shape, device="cuda") * 0.5 + 40.0).to(dtype)
+    fn = bn_ops.bn_act_per_sample if per_sample else bn_ops.bn_act
+    small, plain = make(), make()
+    plain.load_state_dict(small.state_dict())
+    with torch.no_grad():
+        wide = torch.zeros((shape[0], c + 8) + shape[2:], device="cuda", dtype=dtype)
+        got = fn(x, small, True, out=wide[:, 4:4 + c])
+        monkeypatch.setattr(bn_ops, "SMALL_CHANNEL_MAX", 0)
+        want = fn(x, plain, True)
+    assert got.data_ptr() == wide[:, 4:4 + c].data_ptr()
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-5                # bf16: one ulp of the stored result where rounding flips
+    assert (got.float() - want.float()).abs().max().item() <= tol * (want.float().abs().max().item() + 1e-6)
+    assert (wide[:, :4] == 0).all() and (wide[:, 4 + c:] == 0).all()
+    assert torch.allclose(small.running_mean, plain.running_mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(small.running_var, plain.running_var, rtol=1e-4, atol=1e-7)
+    assert small.num_batches_tracked.item() == plain.num_batches_tracked.item() == (shape[0] if per_sample else 1)
