@@ -69,6 +69,9 @@ def parse():
                     help="do not use MIOpen find mode (torch.backends.cudnn.benchmark) for the I3D convolutions; with it the "
                          "solver choice comes from multimodal_gar_amd/miopen_db (24 %% faster I3D than immediate mode)")
     ap.add_argument("--no-overlap", action="store_true", help="run the RGB and LiDAR branches on one stream")
+    ap.add_argument("--i3d-channels-last", action="store_true",
+                    help="keep the I3D activations NDHWC (no MIOpen layout adapters: ~3 ms/step faster at c3, but MIOpen's kernel "
+                         "search adds ~4 minutes to the start-up of a fresh process)")
     ap.add_argument("--no-graph", action="store_true",
                     help="issue every kernel from the host instead of replaying forward + backward from a HIP graph "
                          "(torch.cuda.CUDAGraph; default on: 4-9 %% per step, more on ranks that hold a single clip)")
@@ -302,6 +305,7 @@ def main():
     # frozen I3D on a side stream (no autograd there: DDP-safe).  Only together with the HIP graph: issued eagerly from
     # the host the two-stream step measured 362 ms against 269 ms on one stream (and 257 ms as a graph on two).
     step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
+    step.module.i3d_channels_last = bool(args.i3d_channels_last)
     batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
 
     def barrier():

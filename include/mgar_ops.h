@@ -320,6 +320,26 @@ int mgar_bn_act_fwd_grouped(const float *x, int G, int C, int P, const float *me
                             const float *gamma, const float *beta, int relu, float *y, void *stream);
 int mgar_bn_act_fwd(const float *x, int B, int C, int P, const float *mean, const float *invstd,
                     const float *gamma, const float *beta, int relu, float *y, void *stream);
+/* ---- channels-last (NDHWC) forward kernels for the frozen I3D between its convolutions (csrc/channels_last.hpp) ----
+ * MIOpen's composable-kernel convolutions work in NDHWC and wrap every NCDHW call in two transposes; with the activations
+ * kept channels-last the BatchNorm3d + ReLU (reference model/backbone.py:61-97), MaxPool3dSamePadding (:99-131) and the
+ * Inception concatenation (:227-260) must read / write that layout.  A tensor is (S * R rows, C): S samples, R = T*H*W
+ * positions, channel innermost; C % 4 == 0, C <= 1024.  per_sample: every sample normalised with its own statistics
+ * (mean / invstd have S * C entries), running statistics updated once per sample in order.
+ *   bn_cl_train_stats  workspace: mgar_bn_cl_workspace_floats(S, R, C, per_sample) floats
+ *   bn_cl_act_fwd      y[row * ldy + c]: y may point at a COLUMN SLICE of a wider (rows, ldy) tensor
+ *   bn_act_fwd_to_cl   the same arithmetic reading NCDHW x (S, C, R) and writing NDHWC (where the layout changes: the stem)
+ *   maxpool3d_same_fwd_cl  x (N, T, H, W, C) -> y (N, ceil(T/st), ceil(H/sh), ceil(W/sw), C), TF "same" zero padding */
+long long mgar_bn_cl_workspace_floats(int S, int R, int C, int per_sample);
+int mgar_bn_cl_train_stats(const float *x, int S, int R, int C, int per_sample, float eps, float momentum, float *workspace,
+                           float *mean, float *invstd, float *running_mean, float *running_var,
+                           long long *num_batches_tracked, void *stream);
+int mgar_bn_cl_act_fwd(const float *x, int S, int R, int C, int per_sample, const float *mean, const float *invstd,
+                       const float *gamma, const float *beta, int relu, float *y, int ldy, void *stream);
+int mgar_bn_act_fwd_to_cl(const float *x, int S, int C, int R, int per_sample, const float *mean, const float *invstd,
+                          const float *gamma, const float *beta, int relu, float *y, int ldy, void *stream);
+int mgar_maxpool3d_same_fwd_cl(const float *x, int N, int T, int H, int W, int C, int kt, int kh, int kw, int st, int sh, int sw,
+                               float *y, void *stream);
 /* Training statistics + apply [+ ReLU] in ONE launch for small channels: at most 16 384 elements per channel (B * P, or P with
  * per_sample statistics) and P % 4 == 0, MGAR_EUNSUPPORTED otherwise.  What mgar_bn_train_stats[_grouped] followed by
  * mgar_bn_act_fwd_into computes (forward only; the launch-bound one-clip step has ~45 such BatchNorms in the I3D).
@@ -575,6 +595,15 @@ int mgar_bn_act_fwd_bf16(const void *x, int B, int C, int P, const float *mean, 
                          const float *gamma, const float *beta, int relu, void *y, void *stream);
 int mgar_three_interpolate_batch_into_bf16(int b, int c, int m, int n, const void *points, const int *idx, const float *weight,
                                            void *out, long long out_bstride, void *stream);
+int mgar_bn_cl_train_stats_bf16(const void *x, int S, int R, int C, int per_sample, float eps, float momentum, float *workspace,
+                                float *mean, float *invstd, float *running_mean, float *running_var,
+                                long long *num_batches_tracked, void *stream);
+int mgar_bn_cl_act_fwd_bf16(const void *x, int S, int R, int C, int per_sample, const float *mean, const float *invstd,
+                            const float *gamma, const float *beta, int relu, void *y, int ldy, void *stream);
+int mgar_bn_act_fwd_to_cl_bf16(const void *x, int S, int C, int R, int per_sample, const float *mean, const float *invstd,
+                               const float *gamma, const float *beta, int relu, void *y, int ldy, void *stream);
+int mgar_maxpool3d_same_fwd_cl_bf16(const void *x, int N, int T, int H, int W, int C, int kt, int kh, int kw, int st, int sh,
+                                    int sw, void *y, void *stream);
 int mgar_bn_act_small_bf16(const void *x, int B, int C, int P, int per_sample, float eps, float momentum, const float *gamma,
                            const float *beta, int relu, float *workspace, float *mean, float *invstd, float *running_mean,
                            float *running_var, long long *num_batches_tracked, void *y, long long y_bstride, void *stream);

@@ -75,6 +75,11 @@ _PROTOS = {
     "mgar_pointwise_conv_fwd_stats": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "mgar_query_group_proj_stack_fwd_stats": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
     "mgar_bn_act_maxpool_bwd_strided": [_P, _LL, _LL, _LL, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
+    "mgar_bn_cl_workspace_floats": [_I, _I, _I, _I],
+    "mgar_bn_cl_train_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_bn_cl_act_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "mgar_bn_act_fwd_to_cl": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "mgar_maxpool3d_same_fwd_cl": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_bn_act_small": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P],
     "mgar_bn_act_fwd_into": [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _LL, _P],
     "mgar_bn_act_bwd_rowmajor": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
@@ -114,7 +119,8 @@ _PROTOS = {
 # bf16-payload twins (include/mgar_ops.h, last section): identical argument lists
 for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_query_group_proj_batch_fwd",
            "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
-           "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_small", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
+           "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_small", "mgar_bn_cl_train_stats", "mgar_bn_cl_act_fwd", "mgar_bn_act_fwd_to_cl",
+           "mgar_maxpool3d_same_fwd_cl", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
            "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_batch_into", "mgar_three_interpolate_stack",
            "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]
@@ -124,7 +130,7 @@ _fns = {}
 for _name, _args in _PROTOS.items():
     _fn = getattr(_cdll, _name)  # AttributeError here = the library is stale: rebuild it
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats", "_inverse_items", "_workspace_ints", "_partials_workspace_floats")) else ctypes.c_int
+    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats", "_inverse_items", "_workspace_ints", "_partials_workspace_floats", "bn_cl_workspace_floats")) else ctypes.c_int
     _fns[_name] = _fn
 
 _cdll.mgar_abi_version.restype = ctypes.c_int

@@ -257,6 +257,78 @@ def _slice_stride(out, x):
     return out.stride(0) if out.stride(0) >= inner else None
 
 
+# ---- channels-last (NDHWC) activations of the frozen I3D (csrc/channels_last.hpp) -------------------------------------------
+def is_channels_last_3d(x):
+    return x.dim() == 5 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def _cl_out_slice(out, x):
+    """out = y[:, c0:c0 + C] of a channels-last (N, C_total, T, H, W) tensor with x's shape / dtype -> its row stride C_total."""
+    if out is None or out.shape != x.shape or out.dtype != x.dtype or not out.is_cuda:
+        return None
+    n, c, t, h, w = out.shape
+    ld = out.stride(4)
+    ok = out.stride(1) == 1 and ld >= c and out.stride(3) == w * ld and out.stride(2) == h * w * ld and out.stride(0) == t * h * w * ld
+    return ld if ok and ld % 4 == 0 and (out.data_ptr() // out.element_size()) % 4 == 0 else None
+
+
+def _cl_stats(x, bn, per_sample):
+    n, c, t, h, w = x.shape
+    r = t * h * w
+    rows = n * c if per_sample else c
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    ws = torch.empty((max(L.raw("mgar_bn_cl_workspace_floats", n, r, c, int(per_sample)), 1),), dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    L.payload_call("mgar_bn_cl_train_stats", x.dtype, x.data_ptr(), n, r, c, int(per_sample), float(bn.eps),
+                   float(bn.momentum if bn.momentum is not None else 0.1), L.fptr(ws), L.fptr(mean), L.fptr(invstd),
+                   L.fptr(bn.running_mean) if track else None, L.fptr(bn.running_var) if track else None,
+                   L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
+                   L.stream_of(x))
+    return mean, invstd
+
+
+def bn_act_channels_last(x, bn, relu, per_sample, out=None):
+    """[relu](bn_train(x)) for a channels-last x (forward only; frozen I3D); ``out``: a channel slice of a wider channels-last
+    tensor (the Inception concatenation).  None if the shapes do not qualify (C % 4, C > 1024, dtype)."""
+    n, c, t, h, w = x.shape
+    if c % 4 != 0 or c > 1024 or x.dtype not in _PAYLOADS or (per_sample and n * c > 65535) or not bn.training:
+        return None
+    mean, invstd = _cl_stats(x, bn, per_sample)
+    gamma, beta = _affine(bn, c, x.device)
+    ld = _cl_out_slice(out, x)
+    y = out if ld is not None else torch.empty_like(x)           # preserve_format: channels-last
+    L.payload_call("mgar_bn_cl_act_fwd", x.dtype, x.data_ptr(), n, t * h * w, c, int(per_sample), L.fptr(mean), L.fptr(invstd),
+                   L.fptr(gamma), L.fptr(beta), int(relu), y.data_ptr(), ld if ld is not None else c, L.stream_of(x))
+    return y
+
+
+def bn_act_to_channels_last(x, bn, relu, per_sample):
+    """The same for a contiguous NCDHW x, RESULT channels-last: where the I3D's activations change layout (after the stem)."""
+    x = x.contiguous()
+    n, c, t, h, w = x.shape
+    if x.dtype not in _PAYLOADS or not bn.training or (per_sample and n * c > 65535):
+        return None
+    x3 = x.flatten(2)
+    if per_sample:
+        mean = torch.empty((n * c,), dtype=torch.float32, device=x.device)
+        invstd = torch.empty_like(mean)
+        track = bn.track_running_stats and bn.running_mean is not None
+        ws = _workspace(x3, 1, n * c, x3.shape[2])
+        L.payload_call("mgar_bn_train_stats_grouped", x.dtype, L.pptr(x3, x.dtype), n, c, x3.shape[2], float(bn.eps),
+                       float(bn.momentum if bn.momentum is not None else 0.1), L.fptr(ws), L.fptr(mean), L.fptr(invstd),
+                       L.fptr(bn.running_mean) if track else None, L.fptr(bn.running_var) if track else None,
+                       L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None,
+                       L.stream_of(x))
+    else:
+        mean, invstd = _train_stats(x3, bn)
+    gamma, beta = _affine(bn, c, x.device)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device, memory_format=torch.channels_last_3d)
+    L.payload_call("mgar_bn_act_fwd_to_cl", x.dtype, L.pptr(x3, x.dtype), n, c, t * h * w, int(per_sample), L.fptr(mean), L.fptr(invstd),
+                   L.fptr(gamma), L.fptr(beta), int(relu), y.data_ptr(), c, L.stream_of(x))
+    return y
+
+
 SMALL_CHANNEL_MAX = 16384   # csrc/bn_act.hip, bn_small_fused_kernel: elements per channel one workgroup keeps in registers
 
 
@@ -292,9 +364,15 @@ def _apply_into(x3, bn, relu, mean, invstd, per_sample, out, bstride):
     return out
 
 
-def bn_act(x, bn, relu, rowmajor_grad=False, out=None, in_stats=None):
+def bn_act(x, bn, relu, rowmajor_grad=False, out=None, in_stats=None, to_channels_last=False):
     """[relu](bn(x)) for x (B, C, ...) contiguous on the device; ``bn`` is the nn.BatchNormNd module.
-    ``out``: write the result into this channel slice of a wider tensor (forward-only callers; see _slice_stride)."""
+    ``out``: write the result into this channel slice of a wider tensor (forward-only callers; see _slice_stride).
+    A channels-last 5-D x (forward only) stays channels-last; ``to_channels_last``: NCDHW in, channels-last out."""
+    if x.is_cuda and x.dim() == 5 and not (torch.is_grad_enabled() and (x.requires_grad or (bn.affine and bn.weight.requires_grad))):
+        y = bn_act_channels_last(x, bn, relu, False, out) if is_channels_last_3d(x) else \
+            (bn_act_to_channels_last(x, bn, relu, False) if to_channels_last else None)
+        if y is not None:
+            return y
     x3 = x.contiguous().flatten(2) if x.dim() > 2 else x.contiguous().unsqueeze(-1)
     if not bn.training and torch.is_grad_enabled() and x.requires_grad:
         return None  # eval-mode backward: let the caller take the plain torch path
@@ -311,13 +389,18 @@ def bn_act(x, bn, relu, rowmajor_grad=False, out=None, in_stats=None):
     return _BnAct.apply(x3, gamma, beta, mean, invstd, relu, rowmajor_grad).view(x.shape)
 
 
-def bn_act_per_sample(x, bn, relu, out=None):
+def bn_act_per_sample(x, bn, relu, out=None, to_channels_last=False):
     """[relu](bn(x)) where every sample of x (G, C, ...) is normalised with its own batch statistics and the running
     statistics get the G momentum updates in sample order: G clips through a train-mode BatchNorm in ONE pass, with
     the result of feeding them one at a time.  Forward only (frozen I3D); None if that does not apply."""
     if not (x.is_cuda and x.dtype in _PAYLOADS and bn.training and x.dim() >= 3) or (torch.is_grad_enabled() and
                                                                                         (x.requires_grad or bn.weight.requires_grad)):
         return None
+    if x.dim() == 5:
+        y = bn_act_channels_last(x, bn, relu, True, out) if is_channels_last_3d(x) else \
+            (bn_act_to_channels_last(x, bn, relu, True) if to_channels_last else None)
+        if y is not None:
+            return y
     x3 = x.contiguous().flatten(2)
     g, c, p = x3.shape
     if g * c > 65535:

@@ -953,3 +953,6 @@ BN_API int mgar_bn_stats_from_partials(const float *partial, int nchunk, int C, 
                        mean, invstd, running_mean, running_var, num_batches_tracked, (float *)nullptr);
     return check_launch("bn_stats_from_partials: launch failed");
 }
+
+// the channels-last (NDHWC) variants of the forward kernels, for the frozen I3D between its convolutions
+#include "channels_last.hpp"

@@ -47,9 +47,16 @@ class MaxPool3dSamePadding(nn.MaxPool3d):
         if x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not (torch.is_grad_enabled() and x.requires_grad):
             # forward-only fused kernel (csrc/maxpool3d.hip): no padded copy, no index tensor; fp32 or bf16 payload
             from .. import _lib as L
-            x = x.contiguous()
             n, c, t, h, w = x.shape
             (kt, kh, kw), (st, sh, sw) = self.kernel_size, self.stride
+            if x.dim() == 5 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last_3d) and c % 4 == 0:
+                # channels-last activations stay channels-last (csrc/channels_last.hpp)
+                y = torch.empty((n, c, -(-t // st), -(-h // sh), -(-w // sw)), dtype=x.dtype, device=x.device,
+                                memory_format=torch.channels_last_3d)
+                L.payload_call("mgar_maxpool3d_same_fwd_cl", x.dtype, x.data_ptr(), n, t, h, w, c, kt, kh, kw, st, sh, sw, y.data_ptr(),
+                               L.stream_of(x))
+                return y
+            x = x.contiguous()
             y = torch.empty((n, c, -(-t // st), -(-h // sh), -(-w // sw)), dtype=x.dtype, device=x.device)
             L.payload_call("mgar_maxpool3d_same_fwd", x.dtype, L.pptr(x, x.dtype), n * c, t, h, w, kt, kh, kw, st, sh, sw,
                            L.pptr(y, x.dtype), L.stream_of(x))
@@ -63,6 +70,7 @@ class Unit3D(nn.Module):
     'same' padding."""
 
     per_sample_stats = False   # see InceptionI3d.set_per_sample_stats
+    emit_channels_last = False  # see InceptionI3d.set_channels_last: this unit's BatchNorm writes NDHWC (the stem)
 
     def __init__(self, in_channels, output_channels, kernel_shape=(1, 1, 1), stride=(1, 1, 1), padding=0,
                  activation_fn=F.relu, use_batch_norm=True, use_bias=False, name='unit_3d'):
@@ -126,10 +134,10 @@ class Unit3D(nn.Module):
                 relu_fused = self._activation_fn is F.relu
                 if self.per_sample_stats and x.shape[0] > 1:
                     # several clips in one pass, each normalised with its own statistics = one pass per clip
-                    y = bn_ops.bn_act_per_sample(x, self.bn, relu_fused, out=out)
+                    y = bn_ops.bn_act_per_sample(x, self.bn, relu_fused, out=out, to_channels_last=self.emit_channels_last)
                     assert y is not None, "per_sample_stats is a forward-only (frozen backbone) device path"
                 else:
-                    y = bn_ops.bn_act(x, self.bn, relu_fused, out=out)
+                    y = bn_ops.bn_act(x, self.bn, relu_fused, out=out, to_channels_last=self.emit_channels_last)
             x = self.bn(x) if y is None else y
             relu_fused = relu_fused and y is not None
         if self._activation_fn is not None and not relu_fused:
@@ -158,7 +166,9 @@ class InceptionModule(nn.Module):
             ends = (self.b0, self.b1b, self.b2b, self.b3b)
             widths = [u.conv3d.out_channels for u in ends]
             dt = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
-            y = torch.empty((x.shape[0], sum(widths)) + tuple(x.shape[2:]), dtype=dt, device=x.device)   # 1x1x1 / "same" 3x3x3, stride 1
+            cl = not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last_3d)
+            y = torch.empty((x.shape[0], sum(widths)) + tuple(x.shape[2:]), dtype=dt, device=x.device,   # 1x1x1 / "same" 3x3x3, stride 1
+                            memory_format=torch.channels_last_3d if cl else torch.contiguous_format)
             c0 = 0
             for k, (unit, w) in enumerate(zip(ends, widths)):
                 h = x if k == 0 else (self.b1a(x) if k == 1 else (self.b2a(x) if k == 2 else self.b3a(x)))
@@ -232,6 +242,23 @@ class InceptionI3d(nn.Module):
     def build(self):
         for k, layer in self.end_points.items():
             self.add_module(k, layer)
+
+    def set_channels_last(self, on=True):
+        """Keep the activations NDHWC between the stem and the output (frozen, forward-only device path): MIOpen's
+        composable-kernel convolutions work in that layout and otherwise wrap every call in two transposes (46 launches,
+        5 ms per step at config c3).  The stem's BatchNorm changes the layout; the convolution weights are stored
+        channels-last once (same values, same state dict)."""
+        first = True
+        for end_point, layer in self.end_points.items():
+            for m in layer.modules():
+                if isinstance(m, Unit3D):
+                    if first:
+                        m.emit_channels_last = bool(on)
+                        first = False
+                    elif m.conv3d.weight.dim() == 5:
+                        fmt = torch.channels_last_3d if on else torch.contiguous_format
+                        m.conv3d.weight.data = m.conv3d.weight.data.contiguous(memory_format=fmt)
+        self.channels_last = bool(on)
 
     def set_per_sample_stats(self, on=True):
         """Train-mode BatchNorm statistics per SAMPLE instead of per batch (device, forward-only): a batch of clips

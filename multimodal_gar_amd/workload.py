@@ -129,6 +129,12 @@ class ClipModel(nn.Module):
         self.net.GAR_model.uniform_actor_count = n_actors
         self.overlap_branches = True
         self.batch_i3d = True
+        # Opt-in (bench.py --i3d-channels-last): several clips per I3D pass with the activations NDHWC between the stem and
+        # the RoI crop, so that MIOpen's convolutions need no layout adapters (model/backbone.py,
+        # InceptionI3d.set_channels_last).  Measured at c3: library convolutions 62.5 -> 52.9 ms, this library's BatchNorm /
+        # pooling kernels +3.5 ms in that layout, step 229.4 -> ~226 ms -- but MIOpen's search over its NDHWC kernel
+        # instances takes 4 min 20 s at start-up on a fresh box (NCDHW: 35-40 s), shipped find-db or not, so it is off.
+        self.i3d_channels_last = False
         self._side_stream = self._geo_stream = None
         # What of the trunk's coordinate-only work is issued ahead of the feature path: "fps1" = the level-1 FPS, on the main
         # stream before the I3D launches (round 1); "all" = every level's FPS, ball queries and 3-NN weights on a third
@@ -146,6 +152,8 @@ class ClipModel(nn.Module):
         with torch.no_grad():
             if images.is_cuda and b > 1 and self.batch_i3d:
                 _B, _T, _C, _H, _W = images.shape
+                if self.i3d_channels_last != bool(getattr(rb.backbone_net, "channels_last", False)):
+                    rb.backbone_net.set_channels_last(self.i3d_channels_last)
                 rb.backbone_net.set_per_sample_stats(True)
                 try:
                     crops = rb.crop_features(images.view(_B, _C, _T, _H, _W), [bboxes[i] for i in range(b)])

@@ -361,11 +361,17 @@ def test_forward_bf16_at_full_c2_size_vs_fp32_device_path():
     rec, _ = _record_stage_io(steps["fp32"], batch)
     _check_stages(_stagewise_bf16_errors(steps, rec, per_sample_stats=True), "c2")
     del rec
-    # the same forward replayed from a HIP graph gives the eager result
+    # the same forward replayed from a HIP graph gives the eager result -- up to the convolution library's choice of kernel:
+    # its autotuner settles per process and per call site, and two bf16 kernels for one shape differ in the last bits, which
+    # the random-init BatchNorm chain amplifies to percent level (the fp32 graph-vs-eager identity is asserted exactly in
+    # test_modules_gpu.py::test_train_step_hip_graph_matches_eager)
     steps["bf16"].capture(batch)
     got = steps["bf16"].run(batch)
+    again = [o.clone() for o in steps["bf16"].run(batch)]
     torch.cuda.synchronize()
-    _compare_outputs(got, outs["bf16"], 1e-6)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)                                  # replays are bit-identical
+    _compare_outputs(got, outs["bf16"], BF16_E2E_RMS, rms=True)
 
 
 def test_forward_bf16_at_c5_slice_vs_fp32_device_path():
