@@ -374,6 +374,11 @@ int mgar_bn_act_maxpool_bwd_strided(const float *dpool, long long sb, long long 
                                     const unsigned char *arg, const float *x, const float *xarg, int B, int C, int M,
                                     int nsample, const float *mean, const float *invstd, const float *gamma, int relu,
                                     float *workspace, float *dgamma, float *dbeta, float *dx, void *stream);
+/* mgar_bn_act_bwd without its reduction: coef (2 C) = per channel {mean dz, mean dz xhat} from mgar_pointwise_conv_dw_bnbwd;
+ * rowmajor != 0: dx_t (B * P, C) as mgar_bn_act_bwd_rowmajor (C <= 64). */
+int mgar_bn_act_bwd_apply(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                          const float *gamma, const float *beta, int relu, const float *coef, int rowmajor, float *dx,
+                          void *stream);
 /* mgar_bn_act_bwd with the input gradient written ROW-MAJOR, dx_t (B*P, C), C <= 64: the layout the atomic-free stack
  * grouping backward (mgar_query_group_stack_bwd_rows) gathers from. */
 int mgar_bn_act_bwd_rowmajor(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
@@ -411,6 +416,15 @@ int mgar_pointwise_conv_dw_act(const float *x, const float *dy, int B, int Cin, 
 int mgar_pointwise_conv_fwd(const float *x, int B, int Cin, int P, const float *w, int w_row_stride,
                             int w_col_stride, int Cout, const float *in_mean, const float *in_invstd,
                             const float *in_gamma, const float *in_beta, int in_relu, float *y, void *stream);
+/* Weight gradient of [BatchNorm -> ReLU -> conv 1x1] AND the reduction of that BatchNorm's backward in ONE pass over x (the
+ * layer's pre-BatchNorm input, B x Cin x P) and dy (gradient of the conv output): the kernel accumulates, on the matrix cores,
+ * A[o][i] = sum dy m_i and B[o][i] = sum dy m_i xhat_i (m = ReLU mask, xhat = normalised x); then dW = gamma B + beta A,
+ * dbeta_i = sum_o W A, dgamma_i = sum_o W B, coef = {dbeta, dgamma} / (B * P) for mgar_bn_act_bwd_apply.  Replaces
+ * mgar_pointwise_conv_dw_act + the reduction pass of mgar_bn_act_bwd (8 * B * Cin * P bytes).  Cin, Cout <= 64. */
+int mgar_pointwise_dw_bnbwd_workspace_floats(int B, int Cin, int Cout, int P);
+int mgar_pointwise_conv_dw_bnbwd(const float *x, const float *dy, const float *w, int B, int Cin, int Cout, int P,
+                                 const float *in_mean, const float *in_invstd, const float *in_gamma, const float *in_beta,
+                                 int in_relu, float *workspace, float *dw, float *dgamma, float *dbeta, float *coef, void *stream);
 /* The same, also leaving the statistics partials of y for the BatchNorm that follows: out_stats (Cout, B * P / 128, 2),
  * chunk = 128 (mgar_bn_stats_from_partials).  P % 128 == 0, Cout <= 32 (MGAR_EUNSUPPORTED otherwise). */
 int mgar_pointwise_conv_fwd_stats(const float *x, int B, int Cin, int P, const float *w, int w_row_stride, int w_col_stride,

@@ -90,6 +90,9 @@ _PROTOS = {
     "mgar_bn_act_maxpool_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_pointwise_conv_dw": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "mgar_pointwise_dw_workspace_floats": [_I, _I, _I, _I],
+    "mgar_pointwise_dw_bnbwd_workspace_floats": [_I, _I, _I, _I],
+    "mgar_pointwise_conv_dw_bnbwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_bn_act_bwd_apply": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P],
     "mgar_pointwise_conv_dw_act": [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P],
     "mgar_pointwise_conv_fwd": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_stem_conv3d_workspace_floats": [],

@@ -184,6 +184,24 @@ class _BnActConv(Function):
         cout = w.shape[0]
         gy = gy.contiguous()
         st = L.stream_of(x3)
+        # grad wrt the activated input: W^T gy (the forward kernel, W read transposed, no activation)
+        ga = torch.empty_like(x3)
+        L.call("mgar_pointwise_conv_fwd", L.fptr(gy), b, cout, p, L.fptr(w), 1, c, c, None, None, None, None, 0,
+               L.fptr(ga), st)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        if FUSED_DW_BN_REDUCE and ctx.needs_input_grad[6]:
+            # dW and the BatchNorm backward's reduction {sum dz, sum dz xhat} from ONE pass over (x, gy) on the matrix cores
+            # (csrc/pointwise_dw.hip, pair mode): no reduction pass over (W^T gy, x); then the apply pass alone
+            dw = torch.empty_like(w)
+            coef = torch.empty((2 * c,), dtype=torch.float32, device=x3.device)
+            wsd = torch.empty((max(1, L.raw("mgar_pointwise_dw_bnbwd_workspace_floats", b, c, cout, p)),), dtype=torch.float32,
+                              device=x3.device)
+            L.call("mgar_pointwise_conv_dw_bnbwd", L.fptr(x3), L.fptr(gy), L.fptr(w), b, c, cout, p, L.fptr(mean), L.fptr(invstd),
+                   L.fptr(gamma), L.fptr(beta), int(ctx.relu), L.fptr(wsd), L.fptr(dw), L.fptr(dgamma), L.fptr(dbeta), L.fptr(coef), st)
+            dx = torch.empty((b, p, c) if ctx.rowmajor else (b, c, p), dtype=torch.float32, device=x3.device)
+            L.call("mgar_bn_act_bwd_apply", L.fptr(ga), L.fptr(x3), b, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+                   int(ctx.relu), L.fptr(coef), int(ctx.rowmajor), L.fptr(dx), st)
+            return (dx.permute(0, 2, 1) if ctx.rowmajor else dx), dgamma, dbeta, None, None, None, dw, None, None
         dw = None
         if ctx.needs_input_grad[6]:
             dw = torch.empty_like(w)
@@ -191,11 +209,6 @@ class _BnActConv(Function):
                               device=x3.device)
             L.call("mgar_pointwise_conv_dw_act", L.fptr(x3), L.fptr(gy), b, c, cout, p, L.fptr(mean), L.fptr(invstd),
                    L.fptr(gamma), L.fptr(beta), int(ctx.relu), L.fptr(wsd), L.fptr(dw), st)
-        # grad wrt the activated input: W^T gy (same kernel, W read transposed, no activation)
-        ga = torch.empty_like(x3)
-        L.call("mgar_pointwise_conv_fwd", L.fptr(gy), b, cout, p, L.fptr(w), 1, c, c, None, None, None, None, 0,
-               L.fptr(ga), st)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         ws = _workspace(x3, b, c, p)
         if ctx.rowmajor:
             return _bwd_rowmajor(ga, x3, mean, invstd, gamma, beta, ctx.relu, ws, dgamma, dbeta), dgamma, dbeta, None, None, None, dw, None, None
@@ -205,6 +218,11 @@ class _BnActConv(Function):
         return dx, dgamma, dbeta, None, None, None, dw, None, None
 
 
+# _BnActConv.backward: dW and the BatchNorm-backward reduction from one pass (csrc/pointwise_dw.hip, pair mode) instead of dW,
+# then reduce + apply.  Measured at c3 (round 2): bn_bwd_partial 7.3 -> 3.4 ms per step, but pointwise_dw 6.5 -> 12.6 ms -- the
+# dW kernel is bound by its LDS staging and operand reads, not by HBM, so doubling its (virtual) input channels doubles its
+# time: 228.7 -> 232.5 ms per step.  Kept (tested, tests/test_fused_stats_gpu.py) but off.
+FUSED_DW_BN_REDUCE = False
 FUSED_CONV_MAX_CHANNELS = 64   # csrc/pointwise_fwd.hip: Cout <= 64 in both directions
 
 

@@ -954,5 +954,33 @@ BN_API int mgar_bn_stats_from_partials(const float *partial, int nchunk, int C, 
     return check_launch("bn_stats_from_partials: launch failed");
 }
 
+// BatchNorm [+ ReLU] backward, APPLY ONLY: the reduction {mean dz, mean dz xhat} per channel comes in `coef` (2 C floats) from
+// the kernel that already had the operands in hand (mgar_pointwise_conv_dw_bnbwd).  rowmajor != 0: dx_t (B * P, C), C <= 64.
+BN_API int mgar_bn_act_bwd_apply(const float *dy, const float *x, int B, int C, int P, const float *mean, const float *invstd,
+                                 const float *gamma, const float *beta, int relu, const float *coef, int rowmajor, float *dx,
+                                 void *stream) {
+    MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_bwd_apply: bad sizes");
+    if ((long long)B * C * P == 0) return MGAR_OK;
+    MGAR_REQUIRE(dy && x && mean && invstd && coef && dx, "bn_act_bwd_apply: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    KtScope kt(KT_BN_BWD_APPLY, st, 12.0 * (double)B * C * P);
+    if (rowmajor) {
+        if (C > 64) {
+            set_error("bn_act_bwd_apply: rowmajor needs C <= 64");
+            return MGAR_EUNSUPPORTED;
+        }
+        MGAR_REQUIRE(B <= 65535, "bn_act_bwd_apply: B > 65535");
+        dim3 grid(ceil_div(P, 64), B);
+        if (relu) hipLaunchKernelGGL(bn_bwd_apply_t_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+        else hipLaunchKernelGGL(bn_bwd_apply_t_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    } else {
+        MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS, "bn_act_bwd_apply: C > 65535 or P too large");
+        dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
+        if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, float>), grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, float>), grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
+    }
+    return check_launch("bn_act_bwd_apply: launch failed");
+}
+
 // the channels-last (NDHWC) variants of the forward kernels, for the frozen I3D between its convolutions
 #include "channels_last.hpp"

@@ -101,3 +101,40 @@ def test_stack_grouping_statistics_epilogue_and_module_equivalence():
         close(p, q, "param %d" % i, 2e-4)
     for i, (p, q) in enumerate(zip(a[3], b[3])):
         close(p, q, "buffer %d" % i)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("B,cin,cout,P", [(1, 32, 32, 128 * 600), (3, 16, 24, 4 * 7000), (2, 64, 64, 4 * 9001), (2, 7, 5, 4 * 10000)])
+def test_fused_bn_relu_conv_backward_with_reduction_from_the_dw_kernel(B, cin, cout, P, relu, monkeypatch):
+    """_BnActConv.backward with dW and the BatchNorm-backward reduction from one pass (csrc/pointwise_dw.hip pair mode) against
+    the three-pass form (dW; reduce; apply) and against float64 autograd of the same expression."""
+    from multimodal_gar_amd import bn_ops
+    torch.manual_seed(11)
+    bn = torch.nn.BatchNorm2d(cin).cuda().train()
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+    x = (torch.randn(B, cin, P // 4, 4, device="cuda") * 1.3 + 0.4)
+    cot = torch.randn(B, cout, P // 4, 4, device="cuda")
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(bn_ops, "FUSED_DW_BN_REDUCE", fused)
+        xx = x.clone().requires_grad_(True)
+        bn.zero_grad(); conv.zero_grad()
+        y = bn_ops.bn_act_conv(xx, bn, relu, conv)
+        assert y is not None
+        y.backward(cot)
+        res.append((xx.grad.clone(), conv.weight.grad.clone(), bn.weight.grad.clone(), bn.bias.grad.clone()))
+    # float64 reference
+    x64 = x.double().requires_grad_(True)
+    g64, b64, w64 = (bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True),
+                     conv.weight.detach().double().requires_grad_(True))
+    z = torch.nn.functional.batch_norm(x64, None, None, g64, b64, True, 0.0, bn.eps)
+    z = torch.relu(z) if relu else z
+    torch.nn.functional.conv2d(z, w64).backward(cot.double())
+    want = (x64.grad, w64.grad, g64.grad, b64.grad)
+    for name, got, ref, w in zip(("dx", "dW", "dgamma", "dbeta"), res[0], res[1], want):
+        scale = w.abs().max().item() + 1e-12
+        assert (got.double() - w).abs().max().item() <= 2e-4 * scale, (name, "fused vs float64")
+        assert (got - ref).abs().max().item() <= 2e-4 * scale, (name, "fused vs three-pass")
