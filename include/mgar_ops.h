@@ -575,6 +575,37 @@ int mgar_roipoint_pool3d_fwd(int batch_size, int pts_num, int boxes_num, int fea
                              const float *xyz, const float *boxes3d, const float *pts_feature, float *pooled_features,
                              int *pooled_empty_flag, void *stream);
 
+/* ============================ input preparation ============================
+ * dataloader.py:47-49   transforms.Resize(image_size) + ToTensor() + Normalize(mean, std) of every stitched frame.  Resize on
+ * a PIL image is Pillow's Image.resize(size, BILINEAR) (third-party, un-vendored; src/libImaging/Resample.c restated in
+ * oracle/oracle.py::pil_bilinear_resize and pinned against Pillow itself).
+ *
+ * mgar_image_resample_ksize / _coeffs: HOST helpers -- the per-axis tables of Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc for the bilinear filter: bounds (out_size, 2) int [first tap, taps], kk (out_size, ksize) int, 22-bit
+ * fixed point; in_size == out_size gives the unit table (ksize 1), i.e. the pass Pillow skips.  ksize returns the row length. */
+int mgar_image_resample_ksize(int in_size, int out_size);
+int mgar_image_resample_coeffs(int in_size, int out_size, int *bounds, int *kk);
+/* src (frames, in_h, in_w, 3) uint8 in HBM; xbounds / xkk / ybounds / ykk the DEVICE copies of the tables above for
+ * (in_w -> out_w) and (in_h -> out_h); lut (3, 256) float32: lut[c][v] = the normalised value of byte v in channel c, as the
+ * caller's float32 arithmetic gives it.  Resamples exactly as Pillow does (horizontal pass to bytes, then vertical) and writes
+ * dst[f * dst_frame_stride + c * dst_channel_stride + y * out_w + x] (element strides): dst_kind 0 float32, 1 bfloat16;
+ * dst_kind 2 writes the resampled BYTES, (frames, out_h, out_w, 3), and ignores lut and the strides.
+ * MGAR_EUNSUPPORTED when one tile's source rows do not fit LDS (down-scaling beyond roughly 20x). */
+int mgar_image_resize_normalize_u8(int frames, int in_h, int in_w, int out_h, int out_w, const unsigned char *src,
+                                   const int *xbounds, const int *xkk, const int *ybounds, const int *ykk, const float *lut,
+                                   void *dst, long long dst_frame_stride, long long dst_channel_stride, int dst_kind,
+                                   void *stream);
+/* dataloader.py:119-128 load_pc (upper / lower velodyne moved to the base frame, upper first) followed by the x / y range mask
+ * of mask_points_and_boxes_outside_range (pcdet/datasets/processor/data_processor.py:78-84, common_utils.py:60-63), in one
+ * ordered compaction.  upper (n_upper, C), lower (n_lower, C) float32 rows [x, y, z, features...]; tf_upper / tf_lower HOST
+ * arrays of 12 floats, row-major [R | t]; xy_range HOST array [x_min, y_min, x_max, y_max] (bounds inclusive);
+ * workspace mgar_velodyne_merge_crop_workspace_ints() ints; out (n_upper + n_lower, C) capacity, rows [0, *count) written in
+ * input order; count one int in HBM. */
+long long mgar_velodyne_merge_crop_workspace_ints(int n_upper, int n_lower);
+int mgar_velodyne_merge_crop(int n_upper, int n_lower, int C, const float *upper, const float *lower, const float *tf_upper,
+                             const float *tf_lower, const float *xy_range, int *workspace, float *out, int *count,
+                             void *stream);
+
 /* ============================ bf16 feature payloads (BASELINE configs c2, c5) ============================
  * The reference's kernels are fp32 + int32 only.  For the bf16 configurations SURVEY.md section 8 keeps coordinates,
  * distances, indices and BatchNorm statistics in fp32 / int32 and stores only FEATURE PAYLOADS (and runs the GEMMs) in

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -106,6 +106,11 @@ _PROTOS = {
     "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_points_in_boxes": [_I, _I, _I, _P, _P, _P, _P],
     "mgar_roipoint_pool3d_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_image_resample_ksize": [_I, _I],
+    "mgar_image_resample_coeffs": [_I, _I, _P, _P],
+    "mgar_image_resize_normalize_u8": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _LL, _I, _P],
+    "mgar_velodyne_merge_crop_workspace_ints": [_I, _I],
+    "mgar_velodyne_merge_crop": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_hash_build": [_I, _P, _I, _I, _I, _P, _P, _I, _P],
     "mgar_voxel_hash_lookup": [_I, _P, _I, _I, _I, _P, _P, _I, _P, _P],
     "mgar_spconv_rulebook": [_I, _P, _P, _P, _P, _I, _I, _P, _P],

@@ -24,7 +24,8 @@ const char *const kKtNames[KT_COUNT] = {
     "fps_kernel", "ball_query_kernel", "three_nn_kernel", "three_interp_fwd", "three_interp_bwd", "query_group_fwd",
     "query_group_bwd", "bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel",
     "bn_bwd_apply_kernel", "bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel",
-    "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel", "voxel_roi_pool_fwd", "voxel_roi_pool_bwd", "stem_conv3d_kernel", "query_group_inverse_index"};
+    "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel", "voxel_roi_pool_fwd", "voxel_roi_pool_bwd", "stem_conv3d_kernel", "query_group_inverse_index",
+    "image_resize_normalize"};
 }  // namespace
 
 void kt_begin(int id, hipStream_t st) {
@@ -50,7 +51,7 @@ void kt_end(int id, hipStream_t st, double bytes, double flops) {
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 8; }
+extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 9; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_last_error(void) { return mgar::g_last_error; }
 
 extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on) {

@@ -119,7 +119,7 @@ KERNEL_SOURCES = {
     "ball_query_kernel": "ball_query.hip", "three_nn_kernel": "interpolate.hip", "three_interp_fwd": "interpolate.hip",
     "three_interp_bwd": "interpolate.hip", "query_group_fwd": "query_group.hip", "query_group_bwd": "query_group.hip",
     "voxel_roi_pool_fwd": "voxel_roi_pool.hip", "voxel_roi_pool_bwd": "voxel_roi_pool.hip", "stem_conv3d_kernel": "stem_conv.hip",
-    "query_group_inverse_index": "query_group.hip",
+    "query_group_inverse_index": "query_group.hip", "image_resize_normalize": "input_prep.hip",
 }
 
 

@@ -98,3 +98,105 @@ class VoxelGeneratorWrapper:
         if is_numpy:
             return voxels.numpy(), coords.numpy(), num.numpy()
         return voxels, coords, num
+
+
+class DataProcessor(object):
+    """Mirror of the reference's ``DataProcessor`` (data_processor.py:63-245): a queue of the steps the config names, applied
+    to one frame's ``data_dict`` on the host.  Steps the shipped config uses (Multimodal_cfg/mil3.yaml:47-59):
+    mask_points_and_boxes_outside_range, shuffle_points, transform_points_to_voxels; also sample_points,
+    transform_points_to_voxels_placeholder and calculate_grid_size.  (The device path of the same steps for a whole batch:
+    multimodal_gar_amd/dataloader.py::DeviceClipPrep.)"""
+
+    def __init__(self, processor_configs, point_cloud_range, training, num_point_features):
+        self.point_cloud_range = np.asarray(point_cloud_range, dtype=np.float32)
+        self.training = training
+        self.num_point_features = num_point_features
+        self.mode = 'train' if training else 'test'
+        self.grid_size = self.voxel_size = None
+        self.voxel_generator = None
+        self.data_processor_queue = []
+        for cur_cfg in processor_configs:
+            step = getattr(self, cur_cfg.NAME)
+            step(None, cur_cfg)                                   # the configuration pass (grid size)
+            self.data_processor_queue.append((step, cur_cfg))
+
+    def _grid(self, config):
+        grid = (self.point_cloud_range[3:6] - self.point_cloud_range[0:3]) / np.array(config.VOXEL_SIZE)
+        self.grid_size = np.round(grid).astype(np.int64)
+        self.voxel_size = config.VOXEL_SIZE
+
+    def mask_points_and_boxes_outside_range(self, data_dict=None, config=None):
+        if data_dict is None:
+            return None
+        from ...utils import box_utils, common_utils
+        if data_dict.get('points', None) is not None:
+            mask = common_utils.mask_points_by_range(data_dict['points'], self.point_cloud_range)
+            data_dict['points'] = data_dict['points'][mask]
+        if data_dict.get('gt_boxes', None) is not None and config.REMOVE_OUTSIDE_BOXES and self.training:
+            mask = box_utils.mask_boxes_outside_range_numpy(
+                data_dict['gt_boxes'], self.point_cloud_range, min_num_corners=config.get('min_num_corners', 1),
+                use_center_to_filter=config.get('USE_CENTER_TO_FILTER', True))
+            data_dict['gt_boxes'] = data_dict['gt_boxes'][mask]
+        return data_dict
+
+    def shuffle_points(self, data_dict=None, config=None):
+        if data_dict is None:
+            return None
+        if config.SHUFFLE_ENABLED[self.mode]:
+            points = data_dict['points']
+            data_dict['points'] = points[np.random.permutation(points.shape[0])]
+        return data_dict
+
+    def transform_points_to_voxels_placeholder(self, data_dict=None, config=None):
+        if data_dict is None:
+            return self._grid(config)
+        return data_dict
+
+    def calculate_grid_size(self, data_dict=None, config=None):
+        if data_dict is None:
+            return self._grid(config)
+        return data_dict
+
+    def transform_points_to_voxels(self, data_dict=None, config=None):
+        if data_dict is None:
+            return self._grid(config)
+        if self.voxel_generator is None:
+            self.voxel_generator = VoxelGeneratorWrapper(
+                vsize_xyz=config.VOXEL_SIZE, coors_range_xyz=self.point_cloud_range, num_point_features=self.num_point_features,
+                max_num_points_per_voxel=config.MAX_POINTS_PER_VOXEL, max_num_voxels=config.MAX_NUMBER_OF_VOXELS[self.mode])
+        voxels, coordinates, num_points = self.voxel_generator.generate(data_dict['points'])
+        if not data_dict['use_lead_xyz']:
+            voxels = voxels[..., 3:]
+        data_dict['voxels'] = voxels
+        data_dict['voxel_coords'] = coordinates
+        data_dict['voxel_num_points'] = num_points
+        return data_dict
+
+    def sample_points(self, data_dict=None, config=None):
+        if data_dict is None:
+            return None
+        num_points = config.NUM_POINTS[self.mode]
+        if num_points == -1:
+            return data_dict
+        points = data_dict['points']
+        if num_points < len(points):
+            near = np.linalg.norm(points[:, 0:3], axis=1) < 40.0
+            far_idx, near_idx = np.where(near == 0)[0], np.where(near == 1)[0]
+            if num_points > len(far_idx):                         # every far point, the rest drawn from the near ones
+                near_choice = np.random.choice(near_idx, num_points - len(far_idx), replace=False)
+                choice = np.concatenate((near_choice, far_idx), axis=0) if len(far_idx) > 0 else near_choice
+            else:
+                choice = np.random.choice(np.arange(0, len(points), dtype=np.int32), num_points, replace=False)
+            np.random.shuffle(choice)
+        else:
+            choice = np.arange(0, len(points), dtype=np.int32)
+            if num_points > len(points):
+                choice = np.concatenate((choice, np.random.choice(choice, num_points - len(points), replace=False)), axis=0)
+            np.random.shuffle(choice)
+        data_dict['points'] = points[choice]
+        return data_dict
+
+    def forward(self, data_dict):
+        for step, cfg in self.data_processor_queue:
+            data_dict = step(data_dict, cfg)
+        return data_dict

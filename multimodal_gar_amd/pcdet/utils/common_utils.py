@@ -1,6 +1,7 @@
-"""The three pcdet helpers that feed voxel RoI pooling (reference pcdet/utils/common_utils.py):
-rotate_points_along_z (:35-57), get_voxel_centers (:66-82), generate_voxel2pinds (:235-252).
-torch only; the rest of the reference file (loggers, dist init, SharedArray) is outside the
+"""The pcdet helpers that feed voxel RoI pooling and the input pipeline (reference pcdet/utils/common_utils.py):
+rotate_points_along_z (:35-57), mask_points_by_range (:60-63), get_voxel_centers (:66-82), get_pad_params (:120-137),
+generate_voxel2pinds (:235-252).
+torch / numpy only; the rest of the reference file (loggers, dist init, SharedArray) is outside the
 hot path."""
 import numpy as np
 import torch
@@ -24,6 +25,19 @@ def rotate_points_along_z(points, angle):
     with torch.autocast(device_type=points.device.type, enabled=False):
         out = torch.cat((torch.matmul(points[:, :, 0:3].float(), rot), points[:, :, 3:]), dim=-1)
     return out.numpy() if is_numpy else out
+
+
+def mask_points_by_range(points, limit_range):
+    """points (N, 3 + C), limit_range [x0, y0, z0, x1, y1, z1] -> (N) bool: inside the x / y range, bounds included (z is not
+    tested)."""
+    return (points[:, 0] >= limit_range[0]) & (points[:, 0] <= limit_range[3]) \
+        & (points[:, 1] >= limit_range[1]) & (points[:, 1] <= limit_range[4])
+
+
+def get_pad_params(desired_size, cur_size):
+    """(before, after) for np.pad: everything that is missing goes after."""
+    assert desired_size >= cur_size
+    return (0, desired_size - cur_size)
 
 
 def get_voxel_centers(voxel_coords, downsample_times, voxel_size, point_cloud_range):

@@ -386,3 +386,101 @@ def load_reference_roiaware():
         return mod
     finally:
         sys.setdlopenflags(old)
+
+
+# ---- input pipeline (reference dataloader.py:47-49, 119-131) -----------------------------------
+# The reference resizes every stitched JPEG with torchvision ``transforms.Resize`` on a PIL image, i.e. Pillow's
+# ``Image.resize(size, BILINEAR)`` (third-party: Pillow, un-vendored; requirements.txt pins it).  Pillow's published
+# algorithm (src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc, ImagingResampleHorizontal_8bpc /
+# Vertical_8bpc), restated: a separable triangle filter whose support grows with the down-scaling factor; double-precision
+# weights normalised per output pixel, rounded to 22-bit fixed point; integer accumulation from 1 << 21, arithmetic shift,
+# clamp to a byte; the horizontal pass first, its BYTE result feeding the vertical pass; a pass whose size does not change
+# is skipped.  Pinned against Pillow itself in tests/test_input_pipeline_cpu.py (Pillow is in the image, here and on the
+# GPU box) and by the committed fixture tests/golden/pil_resize_*.npz.
+RESAMPLE_PRECISION_BITS = 32 - 8 - 2
+
+
+def resample_coeffs(in_size, out_size):
+    """-> (bounds (out, 2) int32 [first tap, tap count], kk (out, ksize) int32 fixed-point weights)."""
+    scale = float(in_size) / float(out_size)
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale                                   # bilinear: support 1
+    ksize = int(np.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)                # C's (int) truncates towards zero, as int() does
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = np.zeros(ksize, np.float64)
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w[x] = 1.0 - a if a < 1.0 else 0.0
+        ww = 0.0
+        for x in range(xmax):                                      # the same left-to-right double sum
+            ww += w[x]
+        if ww != 0.0:
+            w[:xmax] = w[:xmax] / ww
+        for x in range(ksize):
+            v = w[x] * (1 << RESAMPLE_PRECISION_BITS)
+            kk[xx, x] = int(-0.5 + v) if w[x] < 0 else int(0.5 + v)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def _resample_axis0(img, out_size):
+    """img (L, ...) uint8 -> (out_size, ...) uint8, resampled along axis 0."""
+    bounds, kk = resample_coeffs(img.shape[0], out_size)
+    out = np.empty((out_size,) + img.shape[1:], np.uint8)
+    src = img.astype(np.int64)
+    for xx in range(out_size):
+        xmin, xmax = int(bounds[xx, 0]), int(bounds[xx, 1])
+        acc = np.full(img.shape[1:], 1 << (RESAMPLE_PRECISION_BITS - 1), np.int64)
+        for x in range(xmax):
+            acc += src[xmin + x] * int(kk[xx, x])
+        out[xx] = np.clip(acc >> RESAMPLE_PRECISION_BITS, 0, 255).astype(np.uint8)
+    return out
+
+
+def pil_bilinear_resize(img, out_h, out_w):
+    """img (H, W, C) uint8 -> (out_h, out_w, C) uint8, what ``PIL.Image.fromarray(img).resize((out_w, out_h), BILINEAR)``
+    returns."""
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    if img.shape[1] != out_w:
+        img = _resample_axis0(img.transpose(1, 0, 2), out_w).transpose(1, 0, 2)
+    if img.shape[0] != out_h:
+        img = _resample_axis0(img, out_h)
+    return np.ascontiguousarray(img)
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def to_tensor_normalize(img, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """img (H, W, 3) uint8 -> (3, H, W) float32: torchvision ToTensor (v / 255 in float32) then Normalize ((x - mean) / std,
+    float32 mean and std, float32 arithmetic) -- dataloader.py:47-49."""
+    x = img.astype(np.float32).transpose(2, 0, 1) / np.float32(255)
+    m = np.asarray(mean, np.float32).reshape(3, 1, 1)
+    s = np.asarray(std, np.float32).reshape(3, 1, 1)
+    return (x - m) / s
+
+
+def velodyne_merge_crop(upper, lower, tf_upper, tf_lower, point_cloud_range):
+    """upper (Nu, C), lower (Nl, C) float32 [x, y, z, features...]; tf_* (3, 4) float32 rigid transforms [R | t] into the base
+    frame -> the merged cloud, upper sensor first (dataloader.py:119-128), with the points outside the x / y range removed
+    in order (mask_points_by_range, pcdet/utils/common_utils.py:60-63).  xyz' = R @ xyz + t in float32, products summed left
+    to right without contraction."""
+    out = []
+    for pts, tf in ((upper, tf_upper), (lower, tf_lower)):
+        pts = np.asarray(pts, np.float32)
+        tf = np.asarray(tf, np.float32)
+        q = pts.copy()
+        for r in range(3):
+            q[:, r] = ((tf[r, 0] * pts[:, 0] + tf[r, 1] * pts[:, 1]) + tf[r, 2] * pts[:, 2]) + tf[r, 3]
+        out.append(q)
+    pc = np.concatenate(out, 0)
+    lim = np.asarray(point_cloud_range, np.float32)
+    keep = (pc[:, 0] >= lim[0]) & (pc[:, 0] <= lim[3]) & (pc[:, 1] >= lim[1]) & (pc[:, 1] <= lim[4])
+    return pc[keep]
