@@ -39,17 +39,25 @@ struct ResizeArgs {
     const float *lut;                        // (3, 256)
     void *dst;
     long long dst_fs, dst_cs;                // element strides of frame and channel (fp32 / bf16 output)
+    long long src_bytes;
     int in_h, in_w, out_h, out_w, xksize, yksize;
-    int th, rows_cap, span_cap;              // output rows per workgroup; LDS row capacity; staged bytes per source row
+    int th, rows_cap, raw_stride;            // output rows per workgroup; LDS row capacity; LDS bytes per staged source row
 };
 
+constexpr int IP_KX = 8;                     // horizontal taps a thread keeps in registers (ksize <= 8: down-scaling below 3.5x)
+
 // OUT: 0 float32 planes, 1 bf16 planes, 2 the resampled bytes themselves, (frames, out_h, out_w, 3)
-template <int OUT>
+// KXR: the horizontal weights of a thread's column live in IP_KX registers (else they are read from the LDS copy)
+//
+// LDS: lut[768] | ytab[th][2 + yksize] | xtab[IP_TW][xksize] (only !KXR) | raw[rows_cap][raw_stride] | mid[rows_cap][3][IP_TW]
+template <int OUT, bool KXR>
 __global__ __launch_bounds__(IP_THREADS) void image_resize_normalize_kernel(ResizeArgs a) {
     extern __shared__ unsigned char lds[];
-    float *lut = reinterpret_cast<float *>(lds);                              // 768 floats
-    unsigned char *raw = lds + 768 * sizeof(float);                           // [rows_cap][span_cap]
-    unsigned char *mid = raw + (size_t)a.rows_cap * a.span_cap;               // [rows_cap][3][IP_TW]
+    float *lut = reinterpret_cast<float *>(lds);
+    int *ytab = reinterpret_cast<int *>(lds + 768 * sizeof(float));
+    int *xtab = ytab + a.th * (2 + a.yksize);
+    unsigned char *raw = reinterpret_cast<unsigned char *>(xtab + (KXR ? 0 : IP_TW * a.xksize));
+    unsigned char *mid = raw + (size_t)a.rows_cap * a.raw_stride;
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * IP_TW, y0 = blockIdx.y * a.th, f = blockIdx.z;
     const int y1 = min(y0 + a.th, a.out_h);
@@ -58,50 +66,106 @@ __global__ __launch_bounds__(IP_THREADS) void image_resize_normalize_kernel(Resi
     const int nrows = a.yb[2 * (y1 - 1)] + a.yb[2 * (y1 - 1) + 1] - r0;       // [r0, last row's first tap + taps)
     const int c0 = a.xb[2 * x0];
     const int span = (a.xb[2 * (x0 + tw - 1)] + a.xb[2 * (x0 + tw - 1) + 1] - c0) * 3;
-    if (nrows > a.rows_cap || span > a.span_cap) return;                      // tables that do not belong to these sizes
+    if (nrows > a.rows_cap || span + 8 > a.raw_stride) return;                // tables that do not belong to these sizes
     if (OUT != 2)
         for (int k = tid; k < 768; k += IP_THREADS) lut[k] = a.lut[k];
-    // 1. the tile's source bytes, once, coalesced
-    const unsigned char *img = a.src + (size_t)f * a.in_h * a.in_w * 3;
-    for (int r = 0; r < nrows; ++r) {
-        const unsigned char *row = img + ((size_t)(r0 + r) * a.in_w + c0) * 3;
-        for (int k = tid; k < span; k += IP_THREADS) raw[r * a.span_cap + k] = row[k];
+    const int yrow = 2 + a.yksize;
+    for (int k = tid; k < (y1 - y0) * yrow; k += IP_THREADS) {
+        const int yy = k / yrow, j = k - yy * yrow;
+        ytab[k] = j < 2 ? a.yb[2 * (y0 + yy) + j] - (j == 0 ? r0 : 0) : a.yk[(size_t)(y0 + yy) * a.yksize + (j - 2)];
+    }
+    if (!KXR)
+        for (int k = tid; k < tw * a.xksize; k += IP_THREADS) xtab[k] = a.xk[(size_t)x0 * a.xksize + k];
+    // 1. the tile's source bytes, once: aligned 4-byte words, eight rows' loads in flight before the first LDS store.  The
+    // word that would cross the end of the buffer is read 1..3 bytes earlier and shifted (no branch, no byte past the end).
+    const uintptr_t src_lo = reinterpret_cast<uintptr_t>(a.src), src_hi = src_lo + (uintptr_t)a.src_bytes;
+    const uintptr_t tile = src_lo + ((size_t)f * a.in_h * a.in_w + (size_t)r0 * a.in_w + c0) * 3;
+    const int words_cap = a.raw_stride >> 2;
+    for (int k = tid; k < words_cap; k += IP_THREADS) {
+        for (int rb = 0; rb < nrows; rb += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uintptr_t row = tile + (size_t)min(rb + u, nrows - 1) * a.in_w * 3;
+                uintptr_t at = (row & ~(uintptr_t)3) + 4 * (uintptr_t)k;
+                at = at + 4 <= src_hi ? at : (at < src_hi ? at : src_hi - 1);          // words past the span: any valid address
+                const int over = at + 4 > src_hi ? (int)(at + 4 - src_hi) : 0;             // 0..3 bytes beyond the end
+                uint32_t w = 0;
+                if (a.src_bytes >= 4) {
+                    __builtin_memcpy(&w, reinterpret_cast<const void *>(at - over), 4);
+                    w >>= 8 * over;
+                } else {                                                               // a source of 3 bytes: one 1 x 1 frame
+                    for (int j = 0; j < 4; ++j)
+                        if (at + j < src_hi) w |= (uint32_t)(*reinterpret_cast<const unsigned char *>(at + j)) << (8 * j);
+                }
+                v[u] = w;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (rb + u < nrows) reinterpret_cast<uint32_t *>(raw + (size_t)(rb + u) * a.raw_stride)[k] = v[u];
+        }
     }
     __syncthreads();
-    // 2. horizontal pass -> bytes; a thread keeps its column (IP_THREADS is a multiple of IP_TW)
-    {
-        const int x = tid % IP_TW;
-        if (x < tw) {
-            const int xmin = a.xb[2 * (x0 + x)] - c0, cnt = a.xb[2 * (x0 + x) + 1];
-            const int *__restrict__ k = a.xk + (size_t)(x0 + x) * a.xksize;
-            for (int e = tid / IP_TW; e < nrows * 3; e += IP_THREADS / IP_TW) {
-                const int r = e / 3, c = e - 3 * r;
-                const unsigned char *p = raw + r * a.span_cap + xmin * 3 + c;
-                int acc = 1 << (IP_BITS - 1);
-                for (int t = 0; t < cnt; ++t) acc += (int)p[3 * t] * k[t];
-                mid[e * IP_TW + x] = (unsigned char)clip8(acc);
+    // 2. horizontal pass -> bytes; a thread keeps its column (IP_THREADS is a multiple of IP_TW) and its weights
+    const int x = tid % IP_TW;
+    if (x < tw) {
+        const int xmin = a.xb[2 * (x0 + x)] - c0, cnt = a.xb[2 * (x0 + x) + 1];
+        int kr[IP_KX];
+        if (KXR) {
+#pragma unroll
+            for (int t = 0; t < IP_KX; ++t) kr[t] = t < cnt ? a.xk[(size_t)(x0 + x) * a.xksize + t] : 0;
+        }
+        const int *kx = xtab + x * a.xksize;
+        for (int r = tid / IP_TW; r < nrows; r += IP_THREADS / IP_TW) {
+            const int off = (int)((tile + (size_t)r * a.in_w * 3) & 3);
+            const unsigned char *p = raw + (size_t)r * a.raw_stride + off + xmin * 3;
+            int a0 = 1 << (IP_BITS - 1), a1 = a0, a2 = a0;
+            if (KXR) {
+#pragma unroll
+                for (int t = 0; t < IP_KX; ++t) {         // taps beyond cnt carry weight 0; their bytes are inside the LDS block
+                    a0 += (int)p[3 * t] * kr[t];
+                    a1 += (int)p[3 * t + 1] * kr[t];
+                    a2 += (int)p[3 * t + 2] * kr[t];
+                }
+            } else {
+                for (int t = 0; t < cnt; ++t) {
+                    const int k = kx[t];
+                    a0 += (int)p[3 * t] * k;
+                    a1 += (int)p[3 * t + 1] * k;
+                    a2 += (int)p[3 * t + 2] * k;
+                }
             }
+            unsigned char *m = mid + (size_t)r * 3 * IP_TW + x;
+            m[0] = (unsigned char)clip8(a0);
+            m[IP_TW] = (unsigned char)clip8(a1);
+            m[2 * IP_TW] = (unsigned char)clip8(a2);
         }
     }
     __syncthreads();
     // 3. vertical pass, table, store
-    {
-        const int x = tid % IP_TW;
-        if (x < tw) {
-            for (int e = tid / IP_TW; e < (y1 - y0) * 3; e += IP_THREADS / IP_TW) {
-                const int yy = e / 3, c = e - 3 * yy, y = y0 + yy;
-                const int ymin = a.yb[2 * y] - r0, cnt = a.yb[2 * y + 1];
-                const int *__restrict__ k = a.yk + (size_t)y * a.yksize;
-                int acc = 1 << (IP_BITS - 1);
-                for (int t = 0; t < cnt; ++t) acc += (int)mid[((ymin + t) * 3 + c) * IP_TW + x] * k[t];
-                const int v = clip8(acc);
-                if (OUT == 2) {
-                    reinterpret_cast<unsigned char *>(a.dst)[(((size_t)f * a.out_h + y) * a.out_w + x0 + x) * 3 + c] = (unsigned char)v;
-                } else {
-                    const float o = lut[c * 256 + v];
-                    const size_t at = (size_t)f * a.dst_fs + (size_t)c * a.dst_cs + (size_t)y * a.out_w + x0 + x;
-                    if (OUT == 0) reinterpret_cast<float *>(a.dst)[at] = o;
-                    else Payload<bf16_t>::st(reinterpret_cast<bf16_t *>(a.dst) + at, o);
+    if (x < tw) {
+        for (int yy = tid / IP_TW; yy < y1 - y0; yy += IP_THREADS / IP_TW) {
+            const int *yt = ytab + yy * yrow;
+            const int ymin = yt[0], cnt = yt[1], y = y0 + yy;
+            const unsigned char *m = mid + (size_t)ymin * 3 * IP_TW + x;
+            int a0 = 1 << (IP_BITS - 1), a1 = a0, a2 = a0;
+            for (int t = 0; t < cnt; ++t) {
+                const int k = yt[2 + t];
+                a0 += (int)m[(3 * t) * IP_TW] * k;
+                a1 += (int)m[(3 * t + 1) * IP_TW] * k;
+                a2 += (int)m[(3 * t + 2) * IP_TW] * k;
+            }
+            const int v[3] = {clip8(a0), clip8(a1), clip8(a2)};
+            if (OUT == 2) {
+                unsigned char *o = reinterpret_cast<unsigned char *>(a.dst) + (((size_t)f * a.out_h + y) * a.out_w + x0 + x) * 3;
+                o[0] = (unsigned char)v[0]; o[1] = (unsigned char)v[1]; o[2] = (unsigned char)v[2];
+            } else {
+                const size_t at = (size_t)f * a.dst_fs + (size_t)y * a.out_w + x0 + x;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float o = lut[c * 256 + v[c]];
+                    if (OUT == 0) reinterpret_cast<float *>(a.dst)[at + (size_t)c * a.dst_cs] = o;
+                    else Payload<bf16_t>::st(reinterpret_cast<bf16_t *>(a.dst) + at + (size_t)c * a.dst_cs, o);
                 }
             }
         }
@@ -263,37 +327,47 @@ MGAR_API int mgar_image_resize_normalize_u8(int frames, int in_h, int in_w, int 
     if (frames == 0) return MGAR_OK;
     MGAR_REQUIRE(src && xbounds && xkk && ybounds && ykk && dst && (lut || dst_kind == 2),
                  "mgar_image_resize_normalize_u8: null pointer");
+    MGAR_REQUIRE((reinterpret_cast<uintptr_t>(src) & 3) == 0, "mgar_image_resize_normalize_u8: src must be 4-byte aligned");
     MGAR_REQUIRE((long long)in_h * in_w * 3 < (1ll << 31) && (long long)out_h * out_w < (1ll << 31) && frames <= 65535,
                  "mgar_image_resize_normalize_u8: frame too large");
     ResizeArgs a;
     a.src = src; a.xb = xbounds; a.xk = xkk; a.yb = ybounds; a.yk = ykk; a.lut = lut; a.dst = dst;
     a.dst_fs = dst_frame_stride; a.dst_cs = dst_channel_stride;
+    a.src_bytes = (long long)frames * in_h * in_w * 3;
     a.in_h = in_h; a.in_w = in_w; a.out_h = out_h; a.out_w = out_w;
     a.xksize = resample_ksize(in_w, out_w);
     a.yksize = resample_ksize(in_h, out_h);
+    const bool kxr = a.xksize <= IP_KX;
     // LDS plan from the filter geometry alone (the tables live on the device): a tile of IP_TW columns touches at most
     // ceil(IP_TW * scale) + ksize source columns, th rows touch at most ceil(th * scale) + ksize source rows
     const double sx = (double)in_w / out_w, sy = (double)in_h / out_h;
-    a.span_cap = (int)fmin((double)in_w, ceil(IP_TW * sx) + a.xksize + 1) * 3;
+    const int span_cap = (int)fmin((double)in_w, ceil(IP_TW * sx) + a.xksize + 1) * 3;
+    a.raw_stride = (span_cap + 8 + 3) & ~3;                        // + the alignment slack of the first and the last word
+    size_t lds = 0;
     int th = 16;
     for (;; th >>= 1) {
         a.rows_cap = (int)fmin((double)in_h, ceil(th * sy) + a.yksize + 1);
-        if ((size_t)a.rows_cap * (a.span_cap + 3 * IP_TW) + 768 * sizeof(float) <= (size_t)IP_LDS_BUDGET) break;
+        lds = 768 * sizeof(float) + sizeof(int) * ((size_t)th * (2 + a.yksize) + (kxr ? 0 : (size_t)IP_TW * a.xksize))
+              + (size_t)a.rows_cap * (a.raw_stride + 3 * IP_TW);
+        if (lds <= (size_t)IP_LDS_BUDGET) break;
         if (th == 1) {
             set_error("mgar_image_resize_normalize_u8: down-scaling factor too large for one LDS tile");
             return MGAR_EUNSUPPORTED;
         }
     }
     a.th = th;
-    const size_t lds = 768 * sizeof(float) + (size_t)a.rows_cap * (a.span_cap + 3 * IP_TW);
     dim3 grid(ceil_div(out_w, IP_TW), ceil_div(out_h, th), frames);
     MGAR_REQUIRE(grid.y <= 65535, "mgar_image_resize_normalize_u8: too many row tiles");
     hipStream_t st = (hipStream_t)stream;
     const double out_bytes = dst_kind == 0 ? 4.0 : (dst_kind == 1 ? 2.0 : 1.0);
     KtScope kt(KT_IMAGE_PREP, st, (double)frames * ((double)in_h * in_w * 3 + (double)out_h * out_w * 3 * out_bytes));
-    if (dst_kind == 0) image_resize_normalize_kernel<0><<<grid, IP_THREADS, lds, st>>>(a);
-    else if (dst_kind == 1) image_resize_normalize_kernel<1><<<grid, IP_THREADS, lds, st>>>(a);
-    else image_resize_normalize_kernel<2><<<grid, IP_THREADS, lds, st>>>(a);
+#define IP_LAUNCH(O) \
+    do { if (kxr) image_resize_normalize_kernel<O, true><<<grid, IP_THREADS, lds, st>>>(a); \
+         else image_resize_normalize_kernel<O, false><<<grid, IP_THREADS, lds, st>>>(a); } while (0)
+    if (dst_kind == 0) IP_LAUNCH(0);
+    else if (dst_kind == 1) IP_LAUNCH(1);
+    else IP_LAUNCH(2);
+#undef IP_LAUNCH
     return check_launch("mgar_image_resize_normalize_u8: launch failed");
 }
 

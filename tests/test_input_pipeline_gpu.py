@@ -150,6 +150,7 @@ def test_loader_batch_drives_the_model(tmp_path):
     root, _ = jrdb_tree.make_tree(tmp_path, n_upper=1400, n_lower=1000)
     cfg = jrdb_tree.loader_config(image_size=(64, 96), num_frames=5, num_points=2048)
     cfg.DATA_PROCESSOR = cfg.DATA_PROCESSOR[:2]                   # PointNet2MSG route: points only
+    cfg.POINT_CLOUD_RANGE = [-12.0, -12.0, -2.0, 12.0, 12.0, 2.0]  # wide enough to keep every sampled point
     raw = JRDB_act(cfg, root, True, jrdb_tree.NUM_ACTIONS, False, device_prep=True)
     batch = DeviceClipPrep(raw)(raw.collate_batch([raw[raw.frames.index((0, 6))]]))
     assert batch[11]["points"].shape == (2048, 5)
