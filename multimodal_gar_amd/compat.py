@@ -1,21 +1,26 @@
 """Import aliases for the reference's caller code.
 
-``train_func.py`` does ``from model.gat_model import *`` / ``from pcdet.config import cfg, ...``
-(train_func.py:20-34).  ``install()`` registers this package's ``model`` and ``pcdet``
-sub-packages under those top-level names so such a script runs unchanged on top of the
-MI355X operator set:
+``train_func.py`` does ``from model.gat_model import *`` / ``from pcdet.config import cfg, ...`` /
+``from dataloader import JRDB_act`` (train_func.py:20-34) and ``dataloader.py`` imports ``data.utils.*``
+(dataloader.py:8-9).  ``install()`` registers this package's ``model``, ``pcdet`` and ``data``
+sub-packages and its ``dataloader`` module under those top-level names so such a script runs
+unchanged on top of the MI355X operator set:
 
     import multimodal_gar_amd.compat as compat; compat.install()
     from model.gat_model import GAR_Fusion_ALL
     from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils
+    from dataloader import JRDB_act
 """
 import importlib
 import importlib.util
 import sys
 
 
+TOPS = ("model", "pcdet", "data", "dataloader")
+
+
 def install(force=False):
-    for top in ("model", "pcdet"):
+    for top in TOPS:
         if top in sys.modules and not force:
             mod = sys.modules[top]
             if not getattr(mod, "__name__", "").startswith("multimodal_gar_amd"):
@@ -35,7 +40,7 @@ class _AliasFinder:
 
     def find_spec(self, fullname, path=None, target=None):
         top = fullname.split(".")[0]
-        if top not in ("model", "pcdet") or fullname in sys.modules:
+        if top not in TOPS or fullname in sys.modules:
             return None
         real = "multimodal_gar_amd." + fullname
         try:

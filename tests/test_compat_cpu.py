@@ -24,6 +24,9 @@ from pcdet.config import cfg, cfg_from_yaml_file
 from pcdet.models import build_network, load_data_to_gpu
 from pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pb
 from pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as ps, voxel_pool_modules, voxel_query_utils
+from pcdet.datasets.processor.data_processor import DataProcessor                 # dataloader.py:10-12
+from pcdet.datasets.processor.point_feature_encoder import PointFeatureEncoder
+from pcdet.models.backbones_3d.vfe.mean_vfe import MeanVFE
 import multimodal_gar_amd.model.gat_model as real
 assert GAR_Fusion_ALL is real.GAR_Fusion_ALL
 for name in ("ball_query", "grouping_operation", "farthest_point_sample", "furthest_point_sample", "gather_operation", "three_nn",
@@ -60,6 +63,26 @@ if yaml_path:
         assert key in names, key
     assert tuple(names["GAR_model.AttFusModule1.WQ_r"].shape) == (512, 512)
     print("built GAR_Fusion_ALL from mil3.yaml: %%.1f M parameters" %% (n / 1e6))
+    # the loader, configured by the same YAML as train_func.py:502-507 does, on a synthetic JRDB tree
+    import tempfile
+    sys.path.insert(0, %(root)r + "/tests")
+    import jrdb_tree
+    from dataloader import JRDB_act                               # train_func.py:20
+    import data.utils.jrdb_transforms as jt                       # dataloader.py:9
+    from data.utils.utils import load_pointcloud                  # dataloader.py:8
+    import multimodal_gar_amd.dataloader as real_loader
+    assert JRDB_act is real_loader.JRDB_act and hasattr(jt, "transform_pts_upper_velodyne_to_base")
+    with tempfile.TemporaryDirectory() as tmp:
+        root, anns = jrdb_tree.make_tree(tmp)
+        aug = c.DATALOADER.train.augmentation
+        ds = JRDB_act(aug, root, True, jrdb_tree.NUM_ACTIONS, aug.get("train_backbone", False))
+        assert list(ds.grid_size) == [2000, 2000, 40] and ds.num_boxes == 100 and ds.num_frames == 15
+        s = ds[2]
+        assert s[0].shape == (15, 3, 720, 1280) and s[1].shape == (100, 4) and s[3].shape == (100, 7) and s[9].shape == (100, 5)
+        assert s[-1]["points"].shape[1] == 4 and len(s[-1]["points"]) <= 35000 and s[-1]["voxels"].shape[1:] == (5, 4)
+        batch = ds.collate_batch([s])
+        assert batch[0].shape == (1, 15, 3, 720, 1280) and batch[-1]["voxel_coords"].shape[1] == 4
+    print("built JRDB_act from mil3.yaml")
 print("compat ok")
 """
 
@@ -80,4 +103,4 @@ def test_compat_install_aliases_reference_import_names():
 @pytest.mark.skipif(not os.path.exists(MIL3), reason="the reference tree (and its mil3.yaml) exists in the build container only")
 def test_compat_install_builds_gar_fusion_all_from_reference_yaml():
     out = _run(MIL3)
-    assert "built GAR_Fusion_ALL from mil3.yaml" in out
+    assert "built GAR_Fusion_ALL from mil3.yaml" in out and "built JRDB_act from mil3.yaml" in out
