@@ -218,6 +218,67 @@ class _BnActConv(Function):
         return dx, dgamma, dbeta, None, None, None, dw, None, None
 
 
+class _PlainConv(Function):
+    """y = W x for the FIRST layer of a shared MLP (no BatchNorm in front of it): csrc/pointwise_fwd.hip with the identity in
+    place of the activation, so the output is written once at streaming rate and -- when a BatchNorm follows -- the kernel
+    leaves that BatchNorm's statistics partials behind (no statistics pass over the widest tensor of the module)."""
+
+    @staticmethod
+    def forward(ctx, x3, w, out_stats=None):
+        b, c, p = x3.shape
+        cout = w.shape[0]
+        w = w.contiguous()
+        dt = x3.dtype
+        y = torch.empty((b, cout, p), dtype=dt, device=x3.device)
+        if out_stats is not None:
+            L.call("mgar_pointwise_conv_fwd_stats", L.fptr(x3), b, c, p, L.fptr(w), c, 1, cout, None, None, None, None, 0,
+                   L.fptr(y), L.fptr(out_stats), L.stream_of(x3))
+        else:
+            L.payload_call("mgar_pointwise_conv_fwd", dt, L.pptr(x3, dt), b, c, p, L.fptr(w), c, 1, cout, None, None, None, None, 0,
+                           L.pptr(y, dt), L.stream_of(x3))
+        ctx.save_for_backward(x3, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x3, w = ctx.saved_tensors
+        b, c, p = x3.shape
+        cout = w.shape[0]
+        gy = gy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x3)
+            L.call("mgar_pointwise_conv_fwd", L.fptr(gy), b, cout, p, L.fptr(w), 1, c, c, None, None, None, None, 0, L.fptr(dx),
+                   L.stream_of(x3))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            wsd = torch.empty((max(1, L.raw("mgar_pointwise_dw_workspace_floats", b, c, cout, p)),), dtype=torch.float32,
+                              device=x3.device)
+            L.call("mgar_pointwise_conv_dw", L.fptr(x3), L.fptr(gy), b, c, cout, p, L.fptr(wsd), L.fptr(dw), L.stream_of(x3))
+        return dx, dw, None
+
+
+PLAIN_CONV_MAX_OUT = 32      # one 32-row output block (csrc/pointwise_fwd.hip OB = 1): above it the library GEMM is as fast
+PLAIN_CONV_MAX_IN = 32
+
+
+def plain_conv(x, conv, want_out_stats=False):
+    """conv(x) for a bias-free kernel-size-1 ``conv`` that has no BatchNorm in front (the first layer of a shared MLP), or None
+    outside the kernel's shapes (the caller takes the library GEMM).  -> y, or (y, statistics partials | None)."""
+    if not (x.is_cuda and x.dtype in _PAYLOADS and x.dim() >= 3 and conv.bias is None):
+        return None
+    if x.dtype != torch.float32 and torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad):
+        return None
+    c, cout = x.shape[1], conv.out_channels
+    x3 = x.contiguous().flatten(2)
+    if c > PLAIN_CONV_MAX_IN or cout > PLAIN_CONV_MAX_OUT or x3.shape[2] % 4 != 0 or x3.shape[0] * x3.shape[2] < (1 << 16):
+        return None
+    out_stats = stats_partial_buffer(x3, cout, x3.shape[0] * x3.shape[2]) if want_out_stats and x3.shape[2] % STATS_TILE == 0 else None
+    y = _PlainConv.apply(x3, _f32(conv.weight).view(cout, c), out_stats).view(x.shape[0], cout, *x.shape[2:])
+    return (y, out_stats) if want_out_stats else y
+
+
 # _BnActConv.backward: dW and the BatchNorm-backward reduction from one pass (csrc/pointwise_dw.hip, pair mode) instead of dW,
 # then reduce + apply.  Measured at c3 (round 2): bn_bwd_partial 7.3 -> 3.4 ms per step, but pointwise_dw 6.5 -> 12.6 ms -- the
 # dW kernel is bound by its LDS staging and operand reads, not by HBM, so doubling its (virtual) input channels doubles its

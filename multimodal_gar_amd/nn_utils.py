@@ -93,8 +93,14 @@ class PointwiseSequential(nn.Sequential):
             # only the layer that consumes the input can hand its gradient back row-major
             rm = rowmajor_input_grad and i == start and x.dim() == 4 and x.shape[0] == 1
             if _is_pointwise(layer):
-                x = conv1x1(layer, x)
-                stats = None
+                # a conv with no BatchNorm in front (the module's first layer): the streaming kernel also leaves the statistics
+                # partials of its output for the BatchNorm that follows
+                feeds_bn = i + 1 < n and isinstance(layers[i + 1], _BN_TYPES) and layers[i + 1].training
+                y = bn_ops.plain_conv(x, layer, want_out_stats=feeds_bn) if x.is_cuda and self.fuse_bn_conv else None
+                if y is not None:
+                    x, stats = y if feeds_bn else (y, None)
+                else:
+                    x, stats = conv1x1(layer, x), None
                 i += 1
             elif isinstance(layer, _BN_TYPES) and x.is_cuda:
                 relu = i + 1 < n and isinstance(layers[i + 1], nn.ReLU)

@@ -138,3 +138,59 @@ def test_fused_bn_relu_conv_backward_with_reduction_from_the_dw_kernel(B, cin, c
         scale = w.abs().max().item() + 1e-12
         assert (got.double() - w).abs().max().item() <= 2e-4 * scale, (name, "fused vs float64")
         assert (got - ref).abs().max().item() <= 2e-4 * scale, (name, "fused vs three-pass")
+
+
+@pytest.mark.parametrize("B,cin,cout,P", [(2, 4, 32, 128 * 300), (1, 4, 16, 128 * 600), (3, 7, 24, 4 * 20001), (1, 32, 32, 128 * 512)])
+def test_first_layer_conv_on_the_streaming_kernel(B, cin, cout, P):
+    """The first conv of a shared MLP (no BatchNorm in front) on csrc/pointwise_fwd.hip with the identity activation:
+    product, statistics partials for the BatchNorm behind it, both gradients -- against torch's convolution."""
+    from multimodal_gar_amd import bn_ops
+    torch.manual_seed(1)
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    x = (torch.randn(B, cin, P // 4, 4, device="cuda") * 2 + 0.5).requires_grad_(True)
+    out = bn_ops.plain_conv(x, conv, want_out_stats=True)
+    assert out is not None
+    y, stats = out
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()
+    ref.load_state_dict(conv.state_dict())
+    want = ref(xr)
+    scale = want.abs().max().item()
+    assert y.shape == want.shape and (y - want).abs().max().item() <= 2e-6 * scale
+    if P % 128 == 0:
+        assert stats is not None and stats.shape == (cout, B * P // 128, 2)
+        bn = torch.nn.BatchNorm2d(cout).cuda().train()
+        with torch.no_grad():
+            m, istd = bn_ops._train_stats(y.detach().flatten(2), bn, stats)
+        _check(m, istd, y.detach().flatten(2), bn.eps, "first layer")
+    else:
+        assert stats is None
+    cot = torch.linspace(-1, 1, y.numel(), device="cuda").view(y.shape)
+    (y * cot).sum().backward()
+    (want * cot).sum().backward()
+    assert (x.grad - xr.grad).abs().max().item() <= 1e-5 * xr.grad.abs().max().item()
+    assert (conv.weight.grad - ref.weight.grad).abs().max().item() <= 2e-5 * ref.weight.grad.abs().max().item()
+    # outside the kernel's shapes the caller keeps the library GEMM
+    assert bn_ops.plain_conv(torch.randn(1, 4, 100, 4, device="cuda"), conv if cin == 4 else torch.nn.Conv2d(4, 8, 1, bias=False).cuda()) is None
+    assert bn_ops.plain_conv(torch.randn(1, 40, 1 << 16, 4, device="cuda"), torch.nn.Conv2d(40, 16, 1, bias=False).cuda()) is None
+
+
+def test_shared_mlp_with_first_layer_kernel_equals_unfused_module():
+    from multimodal_gar_amd.nn_utils import PointwiseSequential
+    import copy
+    torch.manual_seed(2)
+    mlp = PointwiseSequential(torch.nn.Conv2d(4, 16, 1, bias=False), torch.nn.BatchNorm2d(16), torch.nn.ReLU(),
+                              torch.nn.Conv2d(16, 32, 1, bias=False), torch.nn.BatchNorm2d(32), torch.nn.ReLU()).cuda().train()
+    plain = copy.deepcopy(mlp)
+    plain.fuse_bn_conv = False                                   # every BatchNorm computes its own statistics, convs on the library
+    x = torch.randn(2, 4, 4096, 16, device="cuda")
+    res = []
+    for m in (mlp, plain):
+        y = m.forward_maxpool(x.clone())
+        (y * torch.linspace(-1, 1, y.numel(), device="cuda").view(y.shape)).sum().backward()
+        res.append((y.detach(), [p.grad.clone() for p in m.parameters()], [b.clone() for b in m.buffers()]))
+    assert (res[0][0] - res[1][0]).abs().max().item() <= 1e-4 * res[1][0].abs().max().item()
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a - b).abs().max().item() <= 5e-4 * (b.abs().max().item() + 1e-6)
+    for a, b in zip(res[0][2], res[1][2]):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-6)
