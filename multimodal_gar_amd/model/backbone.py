@@ -316,6 +316,14 @@ class NLBlockND(nn.Module):
         if self.mode == 'gaussian':
             theta_x = x.view(n, self.in_channels, -1).permute(0, 2, 1)
             f = torch.matmul(theta_x, x.view(n, self.in_channels, -1))
+        elif self.mode == 'dot' and g_x.shape[1] > self.inter_channels:
+            # f = theta^T phi / P has no softmax, so y = (theta^T phi / P) g = theta^T ((phi g) / P): the (P, P) matrix -- 716 MB
+            # per pass for the 6^3 RoI grids of config c3 -- is never formed; Ci x Ci products instead (same algebra, the
+            # sums in another order)
+            theta_x = conv1x1(self.theta, x).view(n, self.inter_channels, -1).permute(0, 2, 1)
+            phi_g = torch.matmul(conv1x1(self.phi, x).view(n, self.inter_channels, -1), g_x) / g_x.shape[1]   # (N, Ci, Ci)
+            y = torch.matmul(theta_x, phi_g).permute(0, 2, 1).contiguous().view(n, self.inter_channels, *x.size()[2:])
+            return (self.W_z(y) if isinstance(self.W_z, nn.Sequential) else conv1x1(self.W_z, y)) + x
         elif self.mode in ('embedded', 'dot'):
             theta_x = conv1x1(self.theta, x).view(n, self.inter_channels, -1).permute(0, 2, 1)
             f = torch.matmul(theta_x, conv1x1(self.phi, x).view(n, self.inter_channels, -1))  # (N, P, P)

@@ -276,10 +276,12 @@ def test_three_interpolate_batch_and_stack(ops, oracle):
     np.testing.assert_allclose(f.grad.cpu().numpy(), oracle.three_interpolate_grad_stack(g, idx[0], w[0], m), rtol=1e-5, atol=1e-4)
 
 
-@pytest.mark.parametrize("b,c,m,n", [(3, 40, 64, 5000), (2, 5, 300, 900), (1, 16, 1, 77), (2, 33, 4096, 16384)])
+@pytest.mark.parametrize("b,c,m,n", [(3, 40, 64, 5000), (2, 5, 300, 900), (1, 16, 1, 77), (2, 33, 4096, 16384),
+                                     (2, 16, 700, 20001), (1, 17, 5000, 36864), (3, 20, 50, 9217), (2, 18, 9000, 9216)])
 def test_three_interpolate_batch_grad_paths(ops, oracle, b, c, m, n):
     """c >= 16 takes the inverted-index backward (no atomics), c < 16 the LDS-atomic one; the forward
-    stages the known rows in LDS.  Some known points are referenced by nobody, some by many."""
+    stages the known rows in LDS.  Some known points are referenced by nobody, some by many.  Rows longer than 9 216
+    unknown points take the owner-per-known-point kernel (two rows in LDS, or one; runs of a thousand entries at m = 50)."""
     pb = ops[0]
     rng = np.random.default_rng(b * 1000 + c)
     feats = rng.standard_normal((b, c, m)).astype(np.float32)

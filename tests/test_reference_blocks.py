@@ -37,6 +37,31 @@ def test_nlblock_matches_reference(tag, cin, cint, dim):
     close(m(x), G[tag + "_y_train"])
 
 
+def test_nlblock_dot_mode_without_the_pairwise_matrix_equals_the_literal_product():
+    """mode='dot' with more positions than embedding channels takes theta^T ((phi g) / P); the literal (theta^T phi / P) g of
+    reference backbone.py:673-690 gives the same values and gradients (float64: rounding only)."""
+    from multimodal_gar_amd.model.backbone import NLBlockND
+    from multimodal_gar_amd.nn_utils import conv1x1
+    torch.manual_seed(0)
+    m = fill_deterministic(NLBlockND(24, 3, mode='dot', dimension=3, bn_layer=False), seed=5).double()
+    with torch.no_grad():
+        m.W_z.weight.normal_()
+    x = torch.randn(2, 24, 6, 6, 6, dtype=torch.float64, requires_grad=True)
+    y = m(x)
+    xr = x.detach().clone().requires_grad_(True)
+    n, ci = 2, 3
+    g_x = conv1x1(m.g, xr).view(n, ci, -1).permute(0, 2, 1)
+    f = torch.matmul(conv1x1(m.theta, xr).view(n, ci, -1).permute(0, 2, 1), conv1x1(m.phi, xr).view(n, ci, -1))
+    lit = torch.matmul(f / f.size(-1), g_x).permute(0, 2, 1).contiguous().view(n, ci, 6, 6, 6)
+    want = conv1x1(m.W_z, lit) + xr
+    assert f.shape == (2, 216, 216) and torch.allclose(y, want, rtol=1e-12, atol=1e-12)
+    cot = torch.randn_like(y)
+    got_g = torch.autograd.grad((y * cot).sum(), [x] + list(m.parameters()))
+    want_g = torch.autograd.grad((want * cot).sum(), [xr] + list(m.parameters()))
+    for a, b in zip(got_g, want_g):
+        assert torch.allclose(a, b, rtol=1e-10, atol=1e-12)
+
+
 def test_unit3d_same_padding_matches_reference():
     from multimodal_gar_amd.model.backbone import Unit3D
     u = fill_deterministic(Unit3D(3, 8, kernel_shape=[7, 7, 7], stride=(2, 2, 2)), seed=3).eval()
