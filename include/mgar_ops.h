@@ -140,12 +140,6 @@ int mgar_three_interpolate_grad_batch_strided(int b, int c, int n, int m, const 
 int mgar_three_interpolate_grad_sorted_batch_strided(int b, int c, int n, int m, const float *grad_out,
                                                      long long grad_out_bstride, const int *list, float *grad_points,
                                                      void *stream);
-/* The sorted backward for LONG rows (n > 9 216, where fewer than four grad_out rows fit LDS): one owner thread per known point
- * walks its run of `list`.  starts (b * m + 1 ints): exclusive prefix over the whole batch of the number of list entries of
- * every known point (starts[s * m + j] .. starts[s * m + j + 1] bound point j of sample s inside the batch-wide list).
- * grad_points is fully written (unreferenced known points get 0).  Same limits as the sorted entry point. */
-int mgar_three_interpolate_grad_runs_batch_strided(int b, int c, int n, int m, const float *grad_out, long long grad_out_bstride,
-                                                   const int *list, const int *starts, float *grad_points, void *stream);
 
 /* ============== pointnet2_stack: (N1+N2+..., 3|C) + per-sample counts ================= */
 

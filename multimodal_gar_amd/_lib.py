@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -40,7 +40,6 @@ _PROTOS = {
     "mgar_three_interpolate_batch_into": [_I, _I, _I, _I, _P, _P, _P, _P, _LL, _P],
     "mgar_three_interpolate_grad_batch_strided": [_I, _I, _I, _I, _P, _LL, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_sorted_batch_strided": [_I, _I, _I, _I, _P, _LL, _P, _P, _P],
-    "mgar_three_interpolate_grad_runs_batch_strided": [_I, _I, _I, _I, _P, _LL, _P, _P, _P, _P],
     "mgar_ball_query_stack": [_I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_query_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_voxel_query_hash_stack": [_I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P],

@@ -282,80 +282,6 @@ __global__ __launch_bounds__(1024) void three_interp_batch_bwd_sorted_kernel(int
     }
 }
 
-// Backward for LONG rows (n > 9 216: only CH <= 2 rows of grad_out fit LDS, so the segmented scan above -- ~100 instructions
-// per 64 entries whatever CH is -- would be paid c / 2 times; it is VALU-bound there: 2.67 ms for the finest decoder level of
-// config c3).  Same sorted list, plus `starts`: the exclusive prefix of the per-known-point entry counts over the whole batch
-// (b * m + 1 ints).  One thread owns a known point and walks its run in list order (fixed summation order, no atomics, every
-// known point written, also the unreferenced ones); a thread keeps JT points going at once and fetches RU entries of each per
-// round trip, so 16 list loads are in flight per lane while ~6 instructions serve an entry.  Run lengths are skewed (a wave
-// waits for its longest run), but a run of hundreds of entries is still only microseconds.  grid (ceil(c/CH), b)
-template <int CH>
-__global__ __launch_bounds__(1024) void three_interp_batch_bwd_runs_kernel(int c, int n, int m, const float *__restrict__ grad_out,
-                                                                           size_t go_bs, const int2 *__restrict__ list,
-                                                                           const int *__restrict__ starts,
-                                                                           float *__restrict__ grad_points) {
-    extern __shared__ float rows[];  // [CH][n]
-    constexpr int JT = 4, RU = 4;
-    const int c0 = blockIdx.x * CH, bs = blockIdx.y;
-    const int nch = min(CH, c - c0);
-    const float *src = grad_out + (size_t)bs * go_bs + (size_t)c0 * n;
-    if ((n & 3) == 0) {
-        for (int i = threadIdx.x * 4; i < nch * n; i += blockDim.x * 4)
-            *reinterpret_cast<float4 *>(rows + i) = *reinterpret_cast<const float4 *>(src + i);
-    } else {
-        for (int i = threadIdx.x; i < nch * n; i += blockDim.x) rows[i] = src[i];
-    }
-    __syncthreads();
-    const int E = 3 * n;
-    const int2 *L = list + (size_t)bs * E;
-    const int *S = starts + (size_t)bs * m;
-    const int base = bs * E;
-    float *dst = grad_points + ((size_t)bs * c + c0) * m;
-    for (int j0 = 0; j0 < m; j0 += blockDim.x * JT) {
-        int s[JT], e[JT];
-        float acc[JT][CH];
-#pragma unroll
-        for (int k = 0; k < JT; ++k) {
-            const int j = j0 + k * blockDim.x + threadIdx.x;
-            s[k] = j < m ? S[j] - base : 0;
-            e[k] = j < m ? S[j + 1] - base : 0;
-#pragma unroll
-            for (int ch = 0; ch < CH; ++ch) acc[k][ch] = 0.f;
-        }
-        bool more = true;
-        while (more) {
-            int2 en[JT][RU];
-#pragma unroll
-            for (int k = 0; k < JT; ++k)
-#pragma unroll
-                for (int u = 0; u < RU; ++u) en[k][u] = s[k] + u < e[k] ? L[s[k] + u] : make_int2(0, 0);
-            more = false;
-#pragma unroll
-            for (int k = 0; k < JT; ++k) {
-#pragma unroll
-                for (int u = 0; u < RU; ++u)
-                    if (s[k] + u < e[k]) {
-                        const int pt = en[k][u].x & 0xffff;
-                        const float w = __int_as_float(en[k][u].y);
-#pragma unroll
-                        for (int ch = 0; ch < CH; ++ch)
-                            if (ch < nch) acc[k][ch] = acc[k][ch] + rows[(size_t)ch * n + pt] * w;
-                    }
-                s[k] += RU;
-                more = more || s[k] < e[k];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < JT; ++k) {
-            const int j = j0 + k * blockDim.x + threadIdx.x;
-            if (j < m)
-#pragma unroll
-                for (int ch = 0; ch < CH; ++ch)
-                    if (ch < nch) dst[(size_t)ch * m + j] = acc[k][ch];
-        }
-    }
-}
-
 // direct forward (rows that do not fit LDS).  grid (ceil(n/256), ceil(c/TI_CCHUNK), b)
 template <typename T>
 __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int m, int n,
@@ -629,43 +555,6 @@ static void launch_bwd_sorted(int b, int c, int n, int m, const float *grad_out,
     }
     hipLaunchKernelGGL((mgar::three_interp_batch_bwd_sorted_kernel<CH>), dim3(ceil_div(c, CH), b), dim3(n >= 1024 ? 1024 : 256),
                        (size_t)CH * n * sizeof(float), st, c, n, m, grad_out, go_bs, reinterpret_cast<const int2 *>(list), grad_points);
-}
-
-template <int CH>
-static void launch_bwd_runs(int b, int c, int n, int m, const float *grad_out, size_t go_bs, const int *list, const int *starts,
-                            float *grad_points, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)mgar::three_interp_batch_bwd_runs_kernel<CH>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, mgar::TI_LDS_MAX_FLOATS * (int)sizeof(float));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((mgar::three_interp_batch_bwd_runs_kernel<CH>), dim3(ceil_div(c, CH), b), dim3(1024),
-                       (size_t)CH * n * sizeof(float), st, c, n, m, grad_out, go_bs, reinterpret_cast<const int2 *>(list), starts,
-                       grad_points);
-}
-
-extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_runs_batch_strided(int b, int c, int n, int m,
-                                                                                                     const float *grad_out,
-                                                                                                     long long grad_out_bstride,
-                                                                                                     const int *list, const int *starts,
-                                                                                                     float *grad_points, void *stream) {
-    MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_grad_runs_batch: negative size");
-    MGAR_REQUIRE(grad_out_bstride >= (long long)c * n, "three_interpolate_grad_runs_batch: grad_out batch stride smaller than a sample");
-    MGAR_REQUIRE((n & 3) != 0 || (grad_out_bstride % 4 == 0 && (uintptr_t)grad_out % 16 == 0),
-                 "three_interpolate_grad_runs_batch: grad_out slice not 16-byte aligned");
-    MGAR_REQUIRE(b <= 65535 && (long long)b * 3 * n < (1ll << 31), "three_interpolate_grad_runs_batch: batch too large");
-    if ((long long)b * c * m == 0) return MGAR_OK;
-    MGAR_REQUIRE(grad_out && list && starts && grad_points, "three_interpolate_grad_runs_batch: null pointer");
-    if (n == 0 || n > TI_LDS_MAX_FLOATS || m > 65535) {
-        set_error("three_interpolate_grad_runs_batch: needs 1 <= n <= 36864 (LDS row) and m <= 65535 (packed entry)");
-        return MGAR_EUNSUPPORTED;
-    }
-    hipStream_t st = (hipStream_t)stream;
-    KtScope kt(KT_THREE_INTERP_BWD, st, (double)b * (24.0 * n + 4.0 * c * m + 4.0 * c * n));
-    if (2 * n <= TI_LDS_MAX_FLOATS) launch_bwd_runs<2>(b, c, n, m, grad_out, (size_t)grad_out_bstride, list, starts, grad_points, st);
-    else launch_bwd_runs<1>(b, c, n, m, grad_out, (size_t)grad_out_bstride, list, starts, grad_points, st);
-    return check_launch("three_interpolate_grad_runs_batch: launch failed");
 }
 
 extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_grad_sorted_batch_strided(int b, int c, int n, int m,

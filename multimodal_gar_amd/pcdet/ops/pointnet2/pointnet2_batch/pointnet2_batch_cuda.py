@@ -129,17 +129,8 @@ def query_group_proj_grad_wrapper(b, c, n, npoints, nsample, grad_y, idx, grad_z
     return 1
 
 
-RUNS_MIN_ROW = 9217     # rows longer than this leave room for fewer than four of them in LDS (csrc/interpolate.hip)
-
-
-def three_interpolate_grad_sorted_wrapper(b, c, n, m, grad_out, entries, grad_points, grad_out_bstride=None, starts=None):
-    """entries: the sorted inverted index; starts (b * m + 1 int32, optional): where every known point's run begins -- given for
-    long rows (n >= RUNS_MIN_ROW), it selects the owner-per-known-point kernel."""
+def three_interpolate_grad_sorted_wrapper(b, c, n, m, grad_out, entries, grad_points, grad_out_bstride=None):
     ptr, bs = _sliced_ptr(grad_out, grad_out_bstride)
-    if starts is not None and n >= RUNS_MIN_ROW:
-        L.call("mgar_three_interpolate_grad_runs_batch_strided", b, c, n, m, ptr, bs, L.iptr(entries), L.iptr(starts),
-               L.fptr(grad_points), L.stream_of(grad_out))
-        return 1
     L.call("mgar_three_interpolate_grad_sorted_batch_strided", b, c, n, m, ptr, bs, L.iptr(entries), L.fptr(grad_points),
            L.stream_of(grad_out))
     return 1

@@ -153,12 +153,7 @@ def _three_interpolate_backward(grad_out, idx, weight, n_known):
         order = torch.argsort(key.view(-1), stable=True)
         packed = (idx.view(-1)[order] << 16) | ((order // 3) % n_unknown).int()
         entries = torch.stack((packed, weight.reshape(-1)[order].view(torch.int32)), dim=1).contiguous()
-        starts = None
-        if n_unknown >= getattr(pointnet2, "RUNS_MIN_ROW", 1 << 30) and batch * 3 * n_unknown < 2 ** 31:
-            # long rows: where the run of every known point begins (exclusive prefix of the per-point entry counts)
-            # (searchsorted, not bincount: no host synchronisation, so the step stays capturable in a HIP graph)
-            starts = torch.searchsorted(key.view(-1)[order], torch.arange(batch * m + 1, device=idx.device, dtype=key.dtype)).int()
-        pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features, bstride, starts)
+        pointnet2.three_interpolate_grad_sorted_wrapper(batch, chans, n_unknown, m, grad_out, entries, grad_features, bstride)
     elif bstride is not None:
         pointnet2.three_interpolate_grad_wrapper(batch, chans, n_unknown, n_known, grad_out, idx, weight, grad_features, bstride)
     else:

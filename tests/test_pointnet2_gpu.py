@@ -280,8 +280,8 @@ def test_three_interpolate_batch_and_stack(ops, oracle):
                                      (2, 16, 700, 20001), (1, 17, 5000, 36864), (3, 20, 50, 9217), (2, 18, 9000, 9216)])
 def test_three_interpolate_batch_grad_paths(ops, oracle, b, c, m, n):
     """c >= 16 takes the inverted-index backward (no atomics), c < 16 the LDS-atomic one; the forward
-    stages the known rows in LDS.  Some known points are referenced by nobody, some by many.  Rows longer than 9 216
-    unknown points take the owner-per-known-point kernel (two rows in LDS, or one; runs of a thousand entries at m = 50)."""
+    stages the known rows in LDS.  Some known points are referenced by nobody, some by many.  Rows of up to 36 864 unknown
+    points (two rows in LDS, or one), runs of a thousand entries at m = 50."""
     pb = ops[0]
     rng = np.random.default_rng(b * 1000 + c)
     feats = rng.standard_normal((b, c, m)).astype(np.float32)
