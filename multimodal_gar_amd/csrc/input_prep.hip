@@ -28,6 +28,12 @@ constexpr int IP_TW = 128;                   // output columns per workgroup
 constexpr int IP_BITS = 32 - 8 - 2;          // Pillow's PRECISION_BITS for 8-bit channels
 constexpr int IP_LDS_BUDGET = 60 * 1024;
 
+// pixel (8 bits) x weight (<= 2^22, never negative for the triangle filter): a 24-bit multiply-add runs at full rate, the
+// 32-bit v_mul_lo_u32 the plain expression compiles to at a quarter of it
+__device__ __forceinline__ int tap(int acc, unsigned pixel, int weight) {
+    return acc + (int)__umul24(pixel, (unsigned)weight);
+}
+
 __device__ __forceinline__ int clip8(int acc) {
     const int v = acc >> IP_BITS;            // arithmetic shift, then clamp: Pillow's clip8 lookup
     return v < 0 ? 0 : (v > 255 ? 255 : v);
@@ -42,7 +48,20 @@ struct ResizeArgs {
     long long src_bytes;
     int in_h, in_w, out_h, out_w, xksize, yksize;
     int th, rows_cap, raw_stride;            // output rows per workgroup; LDS row capacity; LDS bytes per staged source row
+    int vec4;                                // four neighbouring outputs of a row can go out as one 16-byte (8-byte bf16) store
+    double sx, supx, sy, supy;               // scale and filter support per axis, as precompute_coeffs forms them
 };
+
+// [first tap, first tap + taps) of output index i: the bounds row of the coefficient table, recomputed (same double expressions
+// as resample_coeffs_host) so that a workgroup knows its tile's source extent without a dependent load
+__device__ __forceinline__ void tap_range(int i, int in_size, int out_size, double scale, double support, int &lo, int &hi) {
+    if (in_size == out_size) { lo = i; hi = i + 1; return; }
+    const double center = (i + 0.5) * scale;
+    lo = (int)(center - support + 0.5);
+    if (lo < 0) lo = 0;
+    hi = (int)(center + support + 0.5);
+    if (hi > in_size) hi = in_size;
+}
 
 constexpr int IP_KX = 8;                     // horizontal taps a thread keeps in registers (ksize <= 8: down-scaling below 3.5x)
 
@@ -62,11 +81,24 @@ __global__ __launch_bounds__(IP_THREADS) void image_resize_normalize_kernel(Resi
     const int x0 = blockIdx.x * IP_TW, y0 = blockIdx.y * a.th, f = blockIdx.z;
     const int y1 = min(y0 + a.th, a.out_h);
     const int tw = min(IP_TW, a.out_w - x0);
-    const int r0 = a.yb[2 * y0];                                              // bounds grow with y: the tile's rows are
-    const int nrows = a.yb[2 * (y1 - 1)] + a.yb[2 * (y1 - 1) + 1] - r0;       // [r0, last row's first tap + taps)
-    const int c0 = a.xb[2 * x0];
-    const int span = (a.xb[2 * (x0 + tw - 1)] + a.xb[2 * (x0 + tw - 1) + 1] - c0) * 3;
-    if (nrows > a.rows_cap || span + 8 > a.raw_stride) return;                // tables that do not belong to these sizes
+    int r0, r1, c0, c1, lo, hi;
+    tap_range(y0, a.in_h, a.out_h, a.sy, a.supy, r0, hi);                    // bounds grow with the index: the tile's rows are
+    tap_range(y1 - 1, a.in_h, a.out_h, a.sy, a.supy, lo, r1);                // [first row's first tap, last row's last tap)
+    tap_range(x0, a.in_w, a.out_w, a.sx, a.supx, c0, hi);
+    tap_range(x0 + tw - 1, a.in_w, a.out_w, a.sx, a.supx, lo, c1);
+    const int nrows = r1 - r0, span = (c1 - c0) * 3;
+    if (nrows > a.rows_cap || span + 8 > a.raw_stride) return;                // cannot happen for the launcher's plan
+    // every global load of the tile is issued before the first wait: the column's bounds and weights, the tables, the rows
+    const int x = tid % IP_TW;
+    int xmin = 0, cnt = 0, kr[IP_KX];
+    if (x < tw) {
+        xmin = a.xb[2 * (x0 + x)] - c0;
+        cnt = a.xb[2 * (x0 + x) + 1];
+        if (KXR) {
+#pragma unroll
+            for (int t = 0; t < IP_KX; ++t) kr[t] = t < a.xksize ? a.xk[(size_t)(x0 + x) * a.xksize + t] : 0;   // 0 beyond cnt
+        }
+    }
     if (OUT != 2)
         for (int k = tid; k < 768; k += IP_THREADS) lut[k] = a.lut[k];
     const int yrow = 2 + a.yksize;
@@ -76,63 +108,82 @@ __global__ __launch_bounds__(IP_THREADS) void image_resize_normalize_kernel(Resi
     }
     if (!KXR)
         for (int k = tid; k < tw * a.xksize; k += IP_THREADS) xtab[k] = a.xk[(size_t)x0 * a.xksize + k];
-    // 1. the tile's source bytes, once: aligned 4-byte words, eight rows' loads in flight before the first LDS store.  The
+    // 1. the tile's source bytes, once: aligned 4-byte words, sixteen rows' loads in flight before the first LDS store.  The
     // word that would cross the end of the buffer is read 1..3 bytes earlier and shifted (no branch, no byte past the end).
-    const uintptr_t src_lo = reinterpret_cast<uintptr_t>(a.src), src_hi = src_lo + (uintptr_t)a.src_bytes;
-    const uintptr_t tile = src_lo + ((size_t)f * a.in_h * a.in_w + (size_t)r0 * a.in_w + c0) * 3;
+    // 1. the tile's source bytes, once, as aligned 4-byte words.  A wave takes every fourth row and five 64-word pieces of it at
+    // a time, so twenty loads are in flight per lane before the first LDS store.  Addresses are 32-bit offsets from `ab`, the
+    // frame's start rounded down to a word; the word that would cross the end of the buffer is read 1..3 bytes earlier and
+    // shifted (no byte past the end is touched), words wholly past it read the last word (their bytes are never used).
+    const size_t frame_bytes = (size_t)a.in_h * a.in_w * 3;
+    const unsigned fmis = (unsigned)((f * frame_bytes) & 3);                   // src is word aligned
+    const unsigned char *ab = a.src + (f * frame_bytes - fmis);
+    const long long room = a.src_bytes - (long long)(f * frame_bytes - fmis) - 4;   // largest offset a whole word may start at
+    const int lim = room > 0x7ffffff0ll ? 0x7ffffff0 : (int)room;
+    const unsigned tile_rel = fmis + (unsigned)((r0 * a.in_w + c0) * 3);       // the tile's first byte, relative to ab
+    const unsigned pitch = (unsigned)a.in_w * 3;
     const int words_cap = a.raw_stride >> 2;
-    for (int k = tid; k < words_cap; k += IP_THREADS) {
-        for (int rb = 0; rb < nrows; rb += 8) {
-            uint32_t v[8];
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = IP_THREADS / 64, RQ = 4, KQ = 5;                        // rows x word pieces in flight per lane
+    if (lim >= 0) {
+        for (int rb = 0; rb < nrows; rb += NW * RQ)
+            for (int kb = 0; kb < words_cap; kb += 64 * KQ) {
+                uint32_t v[RQ][KQ];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const uintptr_t row = tile + (size_t)min(rb + u, nrows - 1) * a.in_w * 3;
-                uintptr_t at = (row & ~(uintptr_t)3) + 4 * (uintptr_t)k;
-                at = at + 4 <= src_hi ? at : (at < src_hi ? at : src_hi - 1);          // words past the span: any valid address
-                const int over = at + 4 > src_hi ? (int)(at + 4 - src_hi) : 0;             // 0..3 bytes beyond the end
-                uint32_t w = 0;
-                if (a.src_bytes >= 4) {
-                    __builtin_memcpy(&w, reinterpret_cast<const void *>(at - over), 4);
-                    w >>= 8 * over;
-                } else {                                                               // a source of 3 bytes: one 1 x 1 frame
-                    for (int j = 0; j < 4; ++j)
-                        if (at + j < src_hi) w |= (uint32_t)(*reinterpret_cast<const unsigned char *>(at + j)) << (8 * j);
+                for (int u = 0; u < RQ; ++u) {
+                    const int r = min(rb + wave + NW * u, nrows - 1);
+                    const unsigned al = (tile_rel + (unsigned)r * pitch) & ~3u;
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) {
+                        const int t = (int)al + 4 * (kb + 64 * q + lane);
+                        const int o = min(t, lim);
+                        const int over = min(t - o, 3);
+                        uint32_t w;
+                        __builtin_memcpy(&w, ab + (unsigned)o, 4);
+                        v[u][q] = w >> (8 * over);
+                    }
                 }
-                v[u] = w;
-            }
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (rb + u < nrows) reinterpret_cast<uint32_t *>(raw + (size_t)(rb + u) * a.raw_stride)[k] = v[u];
-        }
+                for (int u = 0; u < RQ; ++u) {
+                    const int r = rb + wave + NW * u;
+#pragma unroll
+                    for (int q = 0; q < KQ; ++q) {
+                        const int k = kb + 64 * q + lane;
+                        if (r < nrows && k < words_cap) reinterpret_cast<uint32_t *>(raw + (size_t)r * a.raw_stride)[k] = v[u][q];
+                    }
+                }
+            }
+    } else {                                                                   // fewer than 4 bytes left: the last 1 x 1 frame
+        if (tid < 4 && (long long)(f * frame_bytes - fmis) + tid < a.src_bytes) raw[tid] = ab[tid];
     }
     __syncthreads();
-    // 2. horizontal pass -> bytes; a thread keeps its column (IP_THREADS is a multiple of IP_TW) and its weights
-    const int x = tid % IP_TW;
+    // 2. horizontal pass -> bytes; a thread keeps its column (IP_THREADS is a multiple of IP_TW) and its weights.  LDS issue is
+    // what bounds this kernel, so the 3 x 8 source bytes of a pixel are fetched as seven aligned words and realigned in
+    // registers (v_alignbyte) instead of 24 byte reads with 3-way bank conflicts.
     if (x < tw) {
-        const int xmin = a.xb[2 * (x0 + x)] - c0, cnt = a.xb[2 * (x0 + x) + 1];
-        int kr[IP_KX];
-        if (KXR) {
-#pragma unroll
-            for (int t = 0; t < IP_KX; ++t) kr[t] = t < cnt ? a.xk[(size_t)(x0 + x) * a.xksize + t] : 0;
-        }
         const int *kx = xtab + x * a.xksize;
         for (int r = tid / IP_TW; r < nrows; r += IP_THREADS / IP_TW) {
-            const int off = (int)((tile + (size_t)r * a.in_w * 3) & 3);
-            const unsigned char *p = raw + (size_t)r * a.raw_stride + off + xmin * 3;
+            const unsigned at = (unsigned)r * a.raw_stride + ((tile_rel + (unsigned)r * pitch) & 3u) + xmin * 3;
             int a0 = 1 << (IP_BITS - 1), a1 = a0, a2 = a0;
             if (KXR) {
+                const uint32_t *pw = reinterpret_cast<const uint32_t *>(raw + (at & ~3u));
+                uint32_t w[7], d[6];
 #pragma unroll
-                for (int t = 0; t < IP_KX; ++t) {         // taps beyond cnt carry weight 0; their bytes are inside the LDS block
-                    a0 += (int)p[3 * t] * kr[t];
-                    a1 += (int)p[3 * t + 1] * kr[t];
-                    a2 += (int)p[3 * t + 2] * kr[t];
+                for (int i = 0; i < 7; ++i) w[i] = pw[i];      // taps beyond cnt carry weight 0; their bytes are inside the LDS block
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], at & 3u);
+#pragma unroll
+                for (int t = 0; t < IP_KX; ++t) {
+                    a0 = tap(a0, (d[(3 * t) >> 2] >> (8 * ((3 * t) & 3))) & 0xffu, kr[t]);
+                    a1 = tap(a1, (d[(3 * t + 1) >> 2] >> (8 * ((3 * t + 1) & 3))) & 0xffu, kr[t]);
+                    a2 = tap(a2, (d[(3 * t + 2) >> 2] >> (8 * ((3 * t + 2) & 3))) & 0xffu, kr[t]);
                 }
             } else {
+                const unsigned char *p = raw + at;
                 for (int t = 0; t < cnt; ++t) {
                     const int k = kx[t];
-                    a0 += (int)p[3 * t] * k;
-                    a1 += (int)p[3 * t + 1] * k;
-                    a2 += (int)p[3 * t + 2] * k;
+                    a0 = tap(a0, p[3 * t], k);
+                    a1 = tap(a1, p[3 * t + 1], k);
+                    a2 = tap(a2, p[3 * t + 2], k);
                 }
             }
             unsigned char *m = mid + (size_t)r * 3 * IP_TW + x;
@@ -142,30 +193,51 @@ __global__ __launch_bounds__(IP_THREADS) void image_resize_normalize_kernel(Resi
         }
     }
     __syncthreads();
-    // 3. vertical pass, table, store
-    if (x < tw) {
-        for (int yy = tid / IP_TW; yy < y1 - y0; yy += IP_THREADS / IP_TW) {
-            const int *yt = ytab + yy * yrow;
-            const int ymin = yt[0], cnt = yt[1], y = y0 + yy;
-            const unsigned char *m = mid + (size_t)ymin * 3 * IP_TW + x;
-            int a0 = 1 << (IP_BITS - 1), a1 = a0, a2 = a0;
-            for (int t = 0; t < cnt; ++t) {
-                const int k = yt[2 + t];
-                a0 += (int)m[(3 * t) * IP_TW] * k;
-                a1 += (int)m[(3 * t + 1) * IP_TW] * k;
-                a2 += (int)m[(3 * t + 2) * IP_TW] * k;
-            }
-            const int v[3] = {clip8(a0), clip8(a1), clip8(a2)};
-            if (OUT == 2) {
-                unsigned char *o = reinterpret_cast<unsigned char *>(a.dst) + (((size_t)f * a.out_h + y) * a.out_w + x0 + x) * 3;
-                o[0] = (unsigned char)v[0]; o[1] = (unsigned char)v[1]; o[2] = (unsigned char)v[2];
-            } else {
-                const size_t at = (size_t)f * a.dst_fs + (size_t)y * a.out_w + x0 + x;
+    // 3. vertical pass, table, store: a thread owns four neighbouring columns of one output row (one LDS word per tap and
+    // channel, 16-byte stores)
+    constexpr int QW = IP_TW / 4;
+    for (int item = tid; item < (y1 - y0) * QW; item += IP_THREADS) {
+        const int yy = item / QW, xq = item - yy * QW, xa = 4 * xq;
+        if (xa >= tw) continue;
+        const int *yt = ytab + yy * yrow;
+        const int ymin = yt[0], ycnt = yt[1], y = y0 + yy;
+        const uint32_t *m32 = reinterpret_cast<const uint32_t *>(mid + (size_t)ymin * 3 * IP_TW) + xq;
+        int acc[3][4];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float o = lut[c * 256 + v[c]];
-                    if (OUT == 0) reinterpret_cast<float *>(a.dst)[at + (size_t)c * a.dst_cs] = o;
-                    else Payload<bf16_t>::st(reinterpret_cast<bf16_t *>(a.dst) + at + (size_t)c * a.dst_cs, o);
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[c][i] = 1 << (IP_BITS - 1);
+        for (int t = 0; t < ycnt; ++t) {
+            const int k = yt[2 + t];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint32_t word = m32[(3 * t + c) * QW];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[c][i] = tap(acc[c][i], (word >> (8 * i)) & 0xffu, k);
+            }
+        }
+        const int live = min(4, tw - xa);
+        if (OUT == 2) {
+            unsigned char *o = reinterpret_cast<unsigned char *>(a.dst) + (((size_t)f * a.out_h + y) * a.out_w + x0 + xa) * 3;
+            for (int i = 0; i < live; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) o[3 * i + c] = (unsigned char)clip8(acc[c][i]);
+        } else {
+            const size_t at = (size_t)f * a.dst_fs + (size_t)y * a.out_w + x0 + xa;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = lut[c * 256 + clip8(acc[c][i])];
+                const size_t e = at + (size_t)c * a.dst_cs;
+                if (OUT == 0) {
+                    float *dp = reinterpret_cast<float *>(a.dst) + e;
+                    if (a.vec4 && live == 4) *reinterpret_cast<float4 *>(dp) = make_float4(o[0], o[1], o[2], o[3]);
+                    else for (int i = 0; i < live; ++i) dp[i] = o[i];
+                } else {
+                    bf16_t *dp = reinterpret_cast<bf16_t *>(a.dst) + e;
+                    if (a.vec4 && live == 4) Payload<bf16_t>::st4(dp, make_float4(o[0], o[1], o[2], o[3]));
+                    else for (int i = 0; i < live; ++i) Payload<bf16_t>::st(dp + i, o[i]);
                 }
             }
         }
@@ -356,6 +428,10 @@ MGAR_API int mgar_image_resize_normalize_u8(int frames, int in_h, int in_w, int 
         }
     }
     a.th = th;
+    a.vec4 = dst_kind != 2 && out_w % 4 == 0 && dst_frame_stride % 4 == 0 && dst_channel_stride % 4 == 0
+             && reinterpret_cast<uintptr_t>(dst) % 16 == 0;
+    a.sx = sx; a.supx = sx < 1.0 ? 1.0 : sx;                       // precompute_coeffs: scale, support = 1.0 * max(scale, 1)
+    a.sy = sy; a.supy = sy < 1.0 ? 1.0 : sy;
     dim3 grid(ceil_div(out_w, IP_TW), ceil_div(out_h, th), frames);
     MGAR_REQUIRE(grid.y <= 65535, "mgar_image_resize_normalize_u8: too many row tiles");
     hipStream_t st = (hipStream_t)stream;

@@ -46,6 +46,16 @@ def test_resized_bytes_equal_pillow(size):
         assert np.array_equal(got[f], _pil(frames[f], oh, ow)), "frame %d" % f
 
 
+@pytest.mark.parametrize("frames,ih,iw,oh,ow", [(5, 1, 1, 2, 3), (1, 1, 1, 4, 4), (3, 7, 5, 9, 11), (4, 3, 3, 3, 3), (2, 31, 211, 17, 130)])
+def test_frames_whose_size_is_not_a_multiple_of_four_bytes(frames, ih, iw, oh, ow):
+    """Frame starts that are not word aligned, the last words of the buffer, sources of a few bytes."""
+    from multimodal_gar_amd import input_ops
+    src = np.random.default_rng(frames * 100 + iw).integers(0, 256, (frames, ih, iw, 3), dtype=np.uint8)
+    got = input_ops.resize_bytes(torch.from_numpy(src).cuda(), (oh, ow)).cpu().numpy()
+    for f in range(frames):
+        assert np.array_equal(got[f], _pil(src[f], oh, ow)), "frame %d" % f
+
+
 def test_too_strong_downscale_is_refused():
     from multimodal_gar_amd import _lib, input_ops
     with pytest.raises(_lib.MgarError):
