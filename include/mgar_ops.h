@@ -557,6 +557,15 @@ int mgar_spconv_gather_gemm(int No, int K, int Cin, int Cout, const float *in, c
 /* Weight gradient: partial (mgar_spconv_dw_chunks(No), K, Cin, Cout) is written; dW = its sum over the first axis
  * (left to the caller: a fixed-order reduction, reproducible). */
 int mgar_spconv_dw_chunks(int No);
+/* The weight gradient over PAIR LISTS (the neighbour table compacted per offset): no work on sites without a neighbour, 64-pair
+ * tiles software-pipelined.  pair_i / pair_o (P) int32: input / output row of every (offset, site) pair, grouped by offset,
+ * ascending output row inside an offset; items (n_items, 4) int32 {offset, first pair, end pair, 0} with at most
+ * mgar_spconv_pair_chunk() pairs each, grouped by ascending offset; item_start (K + 1) int32: first item of every offset.
+ * partial (n_items, Cin, Cout) scratch; dw (K, Cin, Cout) fully written, summed in item order (reproducible).
+ * C_in, C_out powers of two <= 128 (MGAR_EUNSUPPORTED otherwise: mgar_spconv_dw). */
+int mgar_spconv_pair_chunk(void);
+int mgar_spconv_pairs_dw(int n_items, int K, int Cin, int Cout, const float *in, const float *dout, const int *pair_i,
+                         const int *pair_o, const int *items, const int *item_start, float *partial, float *dw, void *stream);
 int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *dout,
                    float *partial, void *stream);
 

@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -117,6 +117,8 @@ _PROTOS = {
     "mgar_spconv_output_keys": [_I, _P, _P, _P, _P],
     "mgar_spconv_gather_gemm": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "mgar_spconv_dw_chunks": [_I],
+    "mgar_spconv_pair_chunk": [],
+    "mgar_spconv_pairs_dw": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_spconv_dw": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_voxel_roi_pool_stats_workspace_doubles": [_I, _I],
     "mgar_voxel_roi_pool_bwd_workspace_floats": [_I, _I],

@@ -51,7 +51,7 @@ void kt_end(int id, hipStream_t st, double bytes, double flops) {
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 9; }
+extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 10; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_last_error(void) { return mgar::g_last_error; }
 
 extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on) {

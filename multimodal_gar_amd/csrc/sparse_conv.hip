@@ -189,7 +189,9 @@ __global__ __launch_bounds__(256) void spconv_gather_gemm_kernel(int No, int K, 
 }
 
 // ---- weight gradient: dW[k] (Cin, Cout) = sum_o in[nbr[o, k], :]^T dout[o, :] ----------------------------------------------
-// grid (nchunk, K); partial[(chunk * K + k)][Cin][Cout]; chunk = SC_DW_CHUNK output rows
+// grid (K, nchunk) -- the K workgroups of one row chunk are neighbours in launch order, so the chunk's dout rows and the input
+// rows around it are fetched from HBM once and then served by L2 / MALL to the other offsets;
+// partial[(chunk * K + k)][Cin][Cout]; chunk = SC_DW_CHUNK output rows
 constexpr int SC_DW_CHUNK = 8192;
 
 __global__ __launch_bounds__(256) void spconv_dw_kernel(int No, int K, int Cin, int Cout, const float *__restrict__ in,
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(int No, int K, int Cin, 
     float *G = A + SC_ROWS * (CinP + 1);              // [SC_ROWS][CoutP + 1]  dout rows
     __shared__ int nbk[SC_ROWS];
     __shared__ int any_flag[2];                        // alternating between tiles: a reader of tile t never meets the reset of t + 1
-    const int k = blockIdx.y;
+    const int k = blockIdx.x, chunk = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l = lane & 31, h = lane >> 5;
     const int nib = CinP / 32, ncb = CoutP / 32, nblk = nib * ncb;     // 32x32 blocks of dW_k; wave w owns blocks w, w+4, ...
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(int No, int K, int Cin, 
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
-    const int row0 = blockIdx.x * SC_DW_CHUNK, row1 = min(No, row0 + SC_DW_CHUNK);
+    const int row0 = chunk * SC_DW_CHUNK, row1 = min(No, row0 + SC_DW_CHUNK);
     int par = 0;
     for (int t0 = row0; t0 < row1; t0 += SC_ROWS, par ^= 1) {
         const int nrow = min(SC_ROWS, row1 - t0);
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(int No, int K, int Cin, 
         }
         // the next tile's first barrier orders these LDS reads before its staging writes
     }
-    float *dst = partial + ((size_t)blockIdx.x * K + k) * Cin * Cout;
+    float *dst = partial + ((size_t)chunk * K + k) * Cin * Cout;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const int blk = wave + 4 * a;
@@ -262,6 +264,132 @@ __global__ __launch_bounds__(256) void spconv_dw_kernel(int No, int K, int Cin, 
             }
         }
     }
+}
+
+// ---- weight gradient over PAIR LISTS ---------------------------------------------------------------------------------------
+// The table form above spends most of its time on sites that have no neighbour under the offset at hand (LiDAR sparsity: ~7 of
+// 27) and on a dependent chain per tile (table column -> gather -> LDS -> MFMA).  Here the caller compacts the table once per
+// rulebook into, per offset k, the list of (input row, output row) pairs in ascending output order (both rows then ascend, so
+// the two gathers are nearly sequential streams), cut into work items of at most SC_PAIR_CHUNK pairs of one offset.  A
+// workgroup owns an item and software-pipelines 64-pair tiles: the indices of tile t + 2 and the rows of tile t + 1 are in
+// flight while tile t is multiplied out of LDS.  dW_k = sum over the pairs of in[i]^T dout[o]; partial per item, summed per
+// offset in item order by spconv_pairs_reduce_kernel (fixed order: reproducible).  C_in, C_out in {1, 2, 4, ..., 128}.
+constexpr int SC_PAIR_CHUNK = 4096;
+// SC_PREF: prefetch registers per operand = 64 rows * max(C_in, C_out) / 256 lanes (4, 8, 16 or 32)
+template <int SC_PREF>
+__global__ __launch_bounds__(256) void spconv_pairs_dw_kernel(int Cin, int Cout, const float *__restrict__ in,
+                                                              const float *__restrict__ dout, const int *__restrict__ pair_i,
+                                                              const int *__restrict__ pair_o, const int4 *__restrict__ items,
+                                                              float *__restrict__ partial) {
+    extern __shared__ float lds[];
+    const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 31) & ~31, ALD = CinP + 1, GLD = CoutP + 1;
+    float *A = lds;                                   // [64][ALD]  gathered input rows
+    float *G = A + SC_ROWS * ALD;                     // [64][GLD]  gathered dout rows
+    __shared__ int idx_i[3][SC_ROWS], idx_o[3][SC_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int4 item = items[blockIdx.x];
+    const int pb = item.y, pe = item.z;
+    const int ntiles = (pe - pb + SC_ROWS - 1) / SC_ROWS;
+    // element mapping of the staging passes (256 % C == 0): pass q covers rows q * rp + tid / C, column tid % C
+    const int ca = tid % Cin, ra = tid / Cin, rpa = 256 / Cin, qa = (SC_ROWS + rpa - 1) / rpa;
+    const int cg = tid % Cout, rg = tid / Cout, rpg = 256 / Cout, qg = (SC_ROWS + rpg - 1) / rpg;
+    for (int e = tid; e < SC_ROWS * (ALD + GLD); e += 256) lds[e] = 0.f;      // the padding columns stay zero
+    const int nib = CinP / 32, ncb = CoutP / 32, nblk = nib * ncb;
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    float a_reg[SC_PREF], g_reg[SC_PREF];
+    int vi = -1, vo = -1;
+    auto load_idx = [&](int t) {
+        const int p = pb + t * SC_ROWS + tid;
+        const bool ok = t < ntiles && tid < SC_ROWS && p < pe;
+        vi = ok ? pair_i[p] : -1;
+        vo = ok ? pair_o[p] : -1;
+    };
+    auto store_idx = [&](int slot) {
+        if (tid < SC_ROWS) { idx_i[slot][tid] = vi; idx_o[slot][tid] = vo; }
+    };
+    auto gather = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < SC_PREF; ++q) {
+            const int r = q * rpa + ra;
+            const int j = (q < qa && r < SC_ROWS) ? idx_i[slot][r] : -1;
+            a_reg[q] = j >= 0 ? in[(size_t)j * Cin + ca] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < SC_PREF; ++q) {
+            const int r = q * rpg + rg;
+            const int j = (q < qg && r < SC_ROWS) ? idx_o[slot][r] : -1;
+            g_reg[q] = j >= 0 ? dout[(size_t)j * Cout + cg] : 0.f;
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < SC_PREF; ++q) {
+            const int r = q * rpa + ra;
+            if (q < qa && r < SC_ROWS) A[r * ALD + ca] = a_reg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < SC_PREF; ++q) {
+            const int r = q * rpg + rg;
+            if (q < qg && r < SC_ROWS) G[r * GLD + cg] = g_reg[q];
+        }
+    };
+    load_idx(0);
+    store_idx(0);
+    load_idx(1);
+    __syncthreads();
+    gather(0);
+    store_idx(1);
+    load_idx(2);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();                              // the previous tile's MFMA reads are done; index slot (t + 1) % 3 is visible
+        put();
+        if (t + 1 < ntiles) gather((t + 1) % 3);      // in flight during this tile's MFMA
+        store_idx((t + 2) % 3);
+        load_idx(t + 3);
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int blk = wave + 4 * a;
+            if (blk < nblk) {
+                const int ib = blk / ncb, cb = blk - ib * ncb;
+#pragma unroll 4
+                for (int sidx = 0; sidx < SC_ROWS / 2; ++sidx) {
+                    const float av = A[(2 * sidx + h) * ALD + ib * 32 + l];
+                    const float bv = G[(2 * sidx + h) * GLD + cb * 32 + l];
+                    acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float *dst = partial + (size_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int blk = wave + 4 * a;
+        if (blk < nblk) {
+            const int ib = blk / ncb, cb = blk - ib * ncb;
+            const int co = cb * 32 + l;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ib * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (ci < Cin && co < Cout) dst[(size_t)ci * Cout + co] = acc[a][r];
+            }
+        }
+    }
+}
+
+// dW[k][e] = sum of partial[item][e] over the items of offset k, in item order.  grid (ceil(Cin * Cout / 256), K)
+__global__ __launch_bounds__(256) void spconv_pairs_reduce_kernel(int elems, const int *__restrict__ item_start,
+                                                                  const float *__restrict__ partial, float *__restrict__ dw) {
+    const int e = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y;
+    if (e >= elems) return;
+    float s = 0.f;
+    for (int it = item_start[k]; it < item_start[k + 1]; ++it) s = s + partial[(size_t)it * elems + e];
+    dw[(size_t)k * elems + e] = s;
 }
 
 static bool sp_geom_ok(const int *g) {
@@ -371,7 +499,7 @@ SP_API int mgar_spconv_gather_gemm(int No, int K, int Cin, int Cout, const float
 SP_API int mgar_spconv_dw_chunks(int No) { return No < 0 ? MGAR_EINVAL : (No + SC_DW_CHUNK - 1) / SC_DW_CHUNK; }
 SP_API int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *dout, float *partial,
                           void *stream) {
-    MGAR_REQUIRE(No >= 0 && K >= 1 && K <= 65535 && Cin >= 1 && Cout >= 1, "spconv_dw: bad sizes");
+    MGAR_REQUIRE(No >= 0 && K >= 1 && K <= 65535 && Cin >= 1 && Cout >= 1 && (No + SC_DW_CHUNK - 1) / SC_DW_CHUNK <= 65535, "spconv_dw: bad sizes");
     if (Cin > SC_MAXC || Cout > SC_MAXC) {
         set_error("spconv_dw: C_in, C_out <= 128");
         return MGAR_EUNSUPPORTED;
@@ -385,7 +513,43 @@ SP_API int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, con
         (void)hipFuncSetAttribute((const void *)spconv_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
-    hipLaunchKernelGGL(spconv_dw_kernel, dim3((No + SC_DW_CHUNK - 1) / SC_DW_CHUNK, K), dim3(256), lds, (hipStream_t)stream, No, K, Cin,
+    hipLaunchKernelGGL(spconv_dw_kernel, dim3(K, (No + SC_DW_CHUNK - 1) / SC_DW_CHUNK), dim3(256), lds, (hipStream_t)stream, No, K, Cin,
                        Cout, in, nbr, dout, partial);
     return check_launch("spconv_dw: launch failed");
+}
+
+// Weight gradient over pair lists (see spconv_pairs_dw_kernel).  pair_i / pair_o (P): input / output row of every (offset, site)
+// pair, grouped by offset, ascending output row inside an offset; items (n_items, 4) int32 {k, first pair, end pair, 0}, at most
+// mgar_spconv_pair_chunk() pairs each, grouped by offset in ascending order; item_start (K + 1): first item of every offset.
+// partial (n_items, Cin, Cout) scratch; dw (K, Cin, Cout) fully written.  C_in, C_out powers of two <= 128
+// (MGAR_EUNSUPPORTED otherwise: use mgar_spconv_dw).
+SP_API int mgar_spconv_pair_chunk(void) { return SC_PAIR_CHUNK; }
+SP_API int mgar_spconv_pairs_dw(int n_items, int K, int Cin, int Cout, const float *in, const float *dout, const int *pair_i,
+                                const int *pair_o, const int *items, const int *item_start, float *partial, float *dw, void *stream) {
+    MGAR_REQUIRE(n_items >= 0 && K >= 1 && K <= 65535 && Cin >= 1 && Cout >= 1, "spconv_pairs_dw: bad sizes");
+    if (Cin > SC_MAXC || Cout > SC_MAXC || (Cin & (Cin - 1)) || (Cout & (Cout - 1))) {
+        set_error("spconv_pairs_dw: C_in, C_out must be powers of two <= 128");
+        return MGAR_EUNSUPPORTED;
+    }
+    MGAR_REQUIRE(item_start && dw && (n_items == 0 || (in && dout && pair_i && pair_o && items && partial)), "spconv_pairs_dw: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_items > 0) {
+        const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 31) & ~31;
+        const size_t lds = (size_t)SC_ROWS * (CinP + 1 + CoutP + 1) * sizeof(float);
+        const int cmax = Cin > Cout ? Cin : Cout;
+        const int4 *it4 = reinterpret_cast<const int4 *>(items);
+        if (cmax <= 16) hipLaunchKernelGGL(spconv_pairs_dw_kernel<4>, dim3(n_items), dim3(256), lds, st, Cin, Cout, in, dout, pair_i, pair_o, it4, partial);
+        else if (cmax <= 32) hipLaunchKernelGGL(spconv_pairs_dw_kernel<8>, dim3(n_items), dim3(256), lds, st, Cin, Cout, in, dout, pair_i, pair_o, it4, partial);
+        else if (cmax <= 64) hipLaunchKernelGGL(spconv_pairs_dw_kernel<16>, dim3(n_items), dim3(256), lds, st, Cin, Cout, in, dout, pair_i, pair_o, it4, partial);
+        else {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void *)spconv_pairs_dw_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(spconv_pairs_dw_kernel<32>, dim3(n_items), dim3(256), lds, st, Cin, Cout, in, dout, pair_i, pair_o, it4, partial);
+        }
+    }
+    hipLaunchKernelGGL(spconv_pairs_reduce_kernel, dim3(ceil_div(Cin * Cout, 256), K), dim3(256), 0, st, Cin * Cout, item_start, partial, dw);
+    return check_launch("spconv_pairs_dw: launch failed");
 }

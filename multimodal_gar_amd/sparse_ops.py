@@ -76,12 +76,36 @@ class Rulebook:
         self.nbr = torch.empty((n_out, self.K), dtype=torch.int32, device=dev)
         L.call("mgar_spconv_rulebook", n_out, L.iptr(self.out_indices), geom, L.dev_ptr(in_hash.keys, torch.int64), L.iptr(in_hash.vals),
                in_hash.capacity, 0, L.iptr(self.nbr), L.stream_of(indices))
+        self._pairs = None
         self.inv = None             # submanifold: the inverse table is the forward one with mirrored offsets
         if not self.subm:
             out_hash = VoxelHash(self.out_indices, self.out_shape)
             self.inv = torch.empty((self.in_indices.shape[0], self.K), dtype=torch.int32, device=dev)
             L.call("mgar_spconv_rulebook", self.in_indices.shape[0], L.iptr(self.in_indices), geom, L.dev_ptr(out_hash.keys, torch.int64),
                    L.iptr(out_hash.vals), out_hash.capacity, 1, L.iptr(self.inv), L.stream_of(indices))
+
+    def pairs(self):
+        """The neighbour table compacted per kernel offset (built once per rulebook, on first use by a backward pass):
+        pair_i / pair_o (P) int32 -- input / output row of every (offset, output site) with a neighbour, grouped by offset,
+        ascending output row inside an offset; items (n_items, 4) int32 {offset, first pair, end pair, 0} of at most
+        mgar_spconv_pair_chunk() pairs; item_start (K + 1) int32."""
+        if self._pairs is None:
+            mask_t = (self.nbr >= 0).t().contiguous()                            # (K, No)
+            counts = mask_t.sum(1).tolist()                                      # one host synchronisation per rulebook
+            ko = torch.nonzero(mask_t)                                           # rows [k, o], k-major, o ascending
+            pair_o = ko[:, 1].int().contiguous()
+            pair_i = self.nbr.t()[mask_t].contiguous()
+            chunk = L.raw("mgar_spconv_pair_chunk")
+            items, item_start, at = [], [0], 0
+            for k, n in enumerate(counts):
+                for b in range(0, n, chunk):
+                    items.append((k, at + b, at + min(b + chunk, n), 0))
+                at += n
+                item_start.append(len(items))
+            dev = self.nbr.device
+            items_t = torch.tensor(items if items else [(0, 0, 0, 0)], dtype=torch.int32).view(-1, 4).to(dev)
+            self._pairs = (pair_i, pair_o, items_t, torch.tensor(item_start, dtype=torch.int32, device=dev), len(items))
+        return self._pairs
 
     def _output_sites(self, geom):
         """Active output sites of a strided convolution: every o = (i + pad - k) / stride that is integral and inside the
@@ -95,6 +119,10 @@ class Rulebook:
         b = uniq // (zo * yo * xo)
         r = uniq % (zo * yo * xo)
         return torch.stack([b, r // (yo * xo), (r % (yo * xo)) // xo, r % xo], 1).int().contiguous()
+
+
+def _pow2(v):
+    return v >= 1 and (v & (v - 1)) == 0
 
 
 def _gather_gemm(n_out, k, cin, cout, feats, nbr, w, flip):
@@ -128,7 +156,14 @@ class _SparseConv(Function):
             wt = w.transpose(1, 2).contiguous()                                   # (K, Cout, Cin)
             table = rb.nbr if rb.subm else rb.inv
             dfeats = _gather_gemm(feats.shape[0], k, cout, cin, dout, table, wt, 1 if rb.subm else 0)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _pow2(cin) and _pow2(cout) and max(cin, cout) <= 128:
+            # pair lists: no work on sites without a neighbour under the offset, tiles software-pipelined (csrc/sparse_conv.hip)
+            pair_i, pair_o, items, item_start, n_items = rb.pairs()
+            part = torch.empty((max(n_items, 1), cin, cout), dtype=torch.float32, device=feats.device)
+            dw = torch.empty((k, cin, cout), dtype=torch.float32, device=feats.device)
+            L.call("mgar_spconv_pairs_dw", n_items, k, cin, cout, L.fptr(feats), L.fptr(dout), L.iptr(pair_i), L.iptr(pair_o), L.iptr(items),
+                   L.iptr(item_start), L.fptr(part), L.fptr(dw), L.stream_of(feats))
+        elif ctx.needs_input_grad[1]:
             n_out = rb.nbr.shape[0]
             nchunk = L.raw("mgar_spconv_dw_chunks", n_out)
             part = torch.empty((max(nchunk, 1), k, cin, cout), dtype=torch.float32, device=feats.device)
