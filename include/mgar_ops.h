@@ -564,6 +564,13 @@ int mgar_spconv_dw_chunks(int No);
  * partial (n_items, Cin, Cout) scratch; dw (K, Cin, Cout) fully written, summed in item order (reproducible).
  * C_in, C_out powers of two <= 128 (MGAR_EUNSUPPORTED otherwise: mgar_spconv_dw). */
 int mgar_spconv_pair_chunk(void);
+/* Forward / data gradient over the same pair lists: for k = 0 .. K-1 in order, dst[pair_dst[p], :] += src[pair_src[p], :] . w[k]
+ * over the pairs of offset k (one launch per offset: under one offset a destination row occurs once, so the update needs no
+ * atomics and the order of the sum over k is fixed).  dst (rows, Cd) ZERO-FILLED by the caller; w (K, Cs, Cd) row-major;
+ * item_start_host: the (K + 1) item offsets as a HOST array.  Forward: (src, pair_src, pair_dst, w) = (in, pair_i, pair_o, W);
+ * data gradient: (dout, pair_o, pair_i, W_k^T) -- no inverse table.  C_s a power of two, C_s, C_d <= 128. */
+int mgar_spconv_pairs_gemm(int K, int Cs, int Cd, const float *src, const int *pair_src, const int *pair_dst, const int *items,
+                           const int *item_start_host, const float *w, float *dst, void *stream);
 int mgar_spconv_pairs_dw(int n_items, int K, int Cin, int Cout, const float *in, const float *dout, const int *pair_i,
                          const int *pair_o, const int *items, const int *item_start, float *partial, float *dw, void *stream);
 int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, const int *nbr, const float *dout,

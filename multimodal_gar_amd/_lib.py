@@ -118,6 +118,7 @@ _PROTOS = {
     "mgar_spconv_gather_gemm": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "mgar_spconv_dw_chunks": [_I],
     "mgar_spconv_pair_chunk": [],
+    "mgar_spconv_pairs_gemm": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_spconv_pairs_dw": [_I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "mgar_spconv_dw": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_voxel_roi_pool_stats_workspace_doubles": [_I, _I],

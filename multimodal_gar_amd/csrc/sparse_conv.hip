@@ -382,6 +382,105 @@ __global__ __launch_bounds__(256) void spconv_pairs_dw_kernel(int Cin, int Cout,
     }
 }
 
+// ---- forward / data gradient over PAIR LISTS -----------------------------------------------------------------------------
+// dst[pair_dst[p], :] += src[pair_src[p], :] . W   for the pairs of ONE kernel offset (W = W_k, C_src x C_dst, row-major).  Under
+// one offset every destination row occurs at most once (o -> i = o * stride - pad + k is injective), so the update is a plain
+// read-modify-write without atomics; the launcher runs the offsets one after the other on the stream, which also fixes the
+// order of the sum over k.  Forward: src = input rows, dst = output rows; data gradient: src = dout rows, dst = input rows,
+// W = W_k^T -- no inverse table.  A workgroup owns an item (<= SC_PAIR_CHUNK pairs): W stays in LDS for the whole item, 64-pair
+// tiles are software-pipelined (rows of tile t + 1 and the old destination values of tile t in flight during the MFMA of t).
+template <int SC_PREF>
+__global__ __launch_bounds__(256) void spconv_pairs_gemm_kernel(int Cs, int Cd, const float *__restrict__ src,
+                                                                const int *__restrict__ pair_src, const int *__restrict__ pair_dst,
+                                                                const int4 *__restrict__ items, const float *__restrict__ w,
+                                                                float *__restrict__ dst) {
+    extern __shared__ float lds[];
+    const int CdP = (Cd + 31) & ~31, CsP = (Cs + 1) & ~1, ALD = CsP + 1;
+    float *A = lds;                                   // [64][ALD]   gathered source rows
+    float *W = A + SC_ROWS * ALD;                     // [CsP][CdP]
+    __shared__ int idx_s[3][SC_ROWS], idx_d[3][SC_ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int4 item = items[blockIdx.x];
+    const int pb = item.y, pe = item.z;
+    const int ntiles = (pe - pb + SC_ROWS - 1) / SC_ROWS;
+    const int ca = tid % Cs, ra = tid / Cs, rpa = 256 / Cs, qa = (SC_ROWS + rpa - 1) / rpa;
+    for (int e = tid; e < SC_ROWS * ALD; e += 256) A[e] = 0.f;                // padding column(s) stay zero
+    for (int e = tid; e < CsP * CdP; e += 256) {
+        const int ci = e / CdP, co = e - ci * CdP;
+        W[e] = (ci < Cs && co < Cd) ? w[(size_t)ci * Cd + co] : 0.f;
+    }
+    const int sb = wave & 1, ncb = CdP / 32;
+    float a_reg[SC_PREF];
+    int vs = -1, vd = -1;
+    auto load_idx = [&](int t) {
+        const int p = pb + t * SC_ROWS + tid;
+        const bool ok = t < ntiles && tid < SC_ROWS && p < pe;
+        vs = ok ? pair_src[p] : -1;
+        vd = ok ? pair_dst[p] : -1;
+    };
+    auto store_idx = [&](int slot) {
+        if (tid < SC_ROWS) { idx_s[slot][tid] = vs; idx_d[slot][tid] = vd; }
+    };
+    auto gather = [&](int slot) {
+#pragma unroll
+        for (int q = 0; q < SC_PREF; ++q) {
+            const int r = q * rpa + ra;
+            const int j = (q < qa && r < SC_ROWS) ? idx_s[slot][r] : -1;
+            a_reg[q] = j >= 0 ? src[(size_t)j * Cs + ca] : 0.f;
+        }
+    };
+    auto put = [&]() {
+#pragma unroll
+        for (int q = 0; q < SC_PREF; ++q) {
+            const int r = q * rpa + ra;
+            if (q < qa && r < SC_ROWS) A[r * ALD + ca] = a_reg[q];
+        }
+    };
+    load_idx(0);
+    store_idx(0);
+    load_idx(1);
+    __syncthreads();
+    gather(0);
+    store_idx(1);
+    load_idx(2);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        put();
+        if (t + 1 < ntiles) gather((t + 1) % 3);
+        store_idx((t + 2) % 3);
+        load_idx(t + 3);
+        __syncthreads();
+        const int slot = t % 3;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int cb = (wave >> 1) + 2 * a;
+            if (cb < ncb) {
+                const int co = cb * 32 + l;
+                float old[16];
+                int row_of[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {                                 // the old destination values: in flight during the MFMA
+                    const int j = idx_d[slot][sb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                    row_of[r] = j;
+                    old[r] = (j >= 0 && co < Cd) ? dst[(size_t)j * Cd + co] : 0.f;
+                }
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                for (int sidx = 0; sidx < CsP / 2; ++sidx) {
+                    const float av = A[(sb * 32 + l) * ALD + 2 * sidx + h];
+                    const float bv = W[(2 * sidx + h) * CdP + co];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (row_of[r] >= 0 && co < Cd) dst[(size_t)row_of[r] * Cd + co] = old[r] + acc[r];
+            }
+        }
+    }
+}
+
 // dW[k][e] = sum of partial[item][e] over the items of offset k, in item order.  grid (ceil(Cin * Cout / 256), K)
 __global__ __launch_bounds__(256) void spconv_pairs_reduce_kernel(int elems, const int *__restrict__ item_start,
                                                                   const float *__restrict__ partial, float *__restrict__ dw) {
@@ -552,4 +651,43 @@ SP_API int mgar_spconv_pairs_dw(int n_items, int K, int Cin, int Cout, const flo
     }
     hipLaunchKernelGGL(spconv_pairs_reduce_kernel, dim3(ceil_div(Cin * Cout, 256), K), dim3(256), 0, st, Cin * Cout, item_start, partial, dw);
     return check_launch("spconv_pairs_dw: launch failed");
+}
+
+// Forward / data gradient over pair lists (see spconv_pairs_gemm_kernel): for k = 0 .. K-1 in order,
+//   dst[pair_dst[p], :] += src[pair_src[p], :] . w[k]   over the pairs of offset k.
+// dst (n_dst, Cd) must be ZERO-FILLED by the caller; w (K, Cs, Cd) row-major; items / pair lists as for mgar_spconv_pairs_dw,
+// item_start_host: the (K + 1) item offsets as a HOST array.  Forward: src = in, pair_src = pair_i, pair_dst = pair_o, w = W;
+// data gradient: src = dout, pair_src = pair_o, pair_dst = pair_i, w = W_k^T.  C_s a power of two <= 128, C_d <= 128.
+SP_API int mgar_spconv_pairs_gemm(int K, int Cs, int Cd, const float *src, const int *pair_src, const int *pair_dst, const int *items,
+                                  const int *item_start_host, const float *w, float *dst, void *stream) {
+    MGAR_REQUIRE(K >= 1 && K <= 65535 && Cs >= 1 && Cd >= 1 && item_start_host, "spconv_pairs_gemm: bad arguments");
+    if (Cs > SC_MAXC || Cd > SC_MAXC || (Cs & (Cs - 1))) {
+        set_error("spconv_pairs_gemm: C_src must be a power of two, both <= 128");
+        return MGAR_EUNSUPPORTED;
+    }
+    if (item_start_host[K] == 0) return MGAR_OK;
+    MGAR_REQUIRE(src && pair_src && pair_dst && items && w && dst, "spconv_pairs_gemm: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int CdP = (Cd + 31) & ~31, CsP = (Cs + 1) & ~1;
+    const size_t lds = ((size_t)SC_ROWS * (CsP + 1) + (size_t)CsP * CdP) * sizeof(float);
+    static size_t attr_lds[4] = {0, 0, 0, 0};
+    const int variant = Cs <= 16 ? 0 : (Cs <= 32 ? 1 : (Cs <= 64 ? 2 : 3));
+    if (lds > 65536 && lds > attr_lds[variant]) {
+        const void *fn = variant == 0 ? (const void *)spconv_pairs_gemm_kernel<4>
+                         : variant == 1 ? (const void *)spconv_pairs_gemm_kernel<8>
+                         : variant == 2 ? (const void *)spconv_pairs_gemm_kernel<16> : (const void *)spconv_pairs_gemm_kernel<32>;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds[variant] = lds;
+    }
+    for (int k = 0; k < K; ++k) {
+        const int n = item_start_host[k + 1] - item_start_host[k];
+        if (n <= 0) continue;
+        const int4 *it = reinterpret_cast<const int4 *>(items) + item_start_host[k];
+        const float *wk = w + (size_t)k * Cs * Cd;
+        if (variant == 0) hipLaunchKernelGGL(spconv_pairs_gemm_kernel<4>, dim3(n), dim3(256), lds, st, Cs, Cd, src, pair_src, pair_dst, it, wk, dst);
+        else if (variant == 1) hipLaunchKernelGGL(spconv_pairs_gemm_kernel<8>, dim3(n), dim3(256), lds, st, Cs, Cd, src, pair_src, pair_dst, it, wk, dst);
+        else if (variant == 2) hipLaunchKernelGGL(spconv_pairs_gemm_kernel<16>, dim3(n), dim3(256), lds, st, Cs, Cd, src, pair_src, pair_dst, it, wk, dst);
+        else hipLaunchKernelGGL(spconv_pairs_gemm_kernel<32>, dim3(n), dim3(256), lds, st, Cs, Cd, src, pair_src, pair_dst, it, wk, dst);
+    }
+    return check_launch("spconv_pairs_gemm: launch failed");
 }

@@ -77,18 +77,27 @@ class Rulebook:
         L.call("mgar_spconv_rulebook", n_out, L.iptr(self.out_indices), geom, L.dev_ptr(in_hash.keys, torch.int64), L.iptr(in_hash.vals),
                in_hash.capacity, 0, L.iptr(self.nbr), L.stream_of(indices))
         self._pairs = None
-        self.inv = None             # submanifold: the inverse table is the forward one with mirrored offsets
-        if not self.subm:
+        self._geom = geom
+        self.inv = None             # built on demand (inverse_table): only the table-driven data gradient of a strided conv reads it
+
+    def inverse_table(self):
+        """(N_in, K) int32: the output row input i reaches through offset k, or -1 (strided convolutions; a submanifold one uses
+        its forward table with mirrored offsets)."""
+        if self.inv is None and not self.subm:
+            dev = self.in_indices.device
             out_hash = VoxelHash(self.out_indices, self.out_shape)
             self.inv = torch.empty((self.in_indices.shape[0], self.K), dtype=torch.int32, device=dev)
-            L.call("mgar_spconv_rulebook", self.in_indices.shape[0], L.iptr(self.in_indices), geom, L.dev_ptr(out_hash.keys, torch.int64),
-                   L.iptr(out_hash.vals), out_hash.capacity, 1, L.iptr(self.inv), L.stream_of(indices))
+            L.call("mgar_spconv_rulebook", self.in_indices.shape[0], L.iptr(self.in_indices), self._geom,
+                   L.dev_ptr(out_hash.keys, torch.int64), L.iptr(out_hash.vals), out_hash.capacity, 1, L.iptr(self.inv),
+                   L.stream_of(self.in_indices))
+        return self.inv
 
     def pairs(self):
-        """The neighbour table compacted per kernel offset (built once per rulebook, on first use by a backward pass):
+        """The neighbour table compacted per kernel offset (built once per rulebook, on first use):
         pair_i / pair_o (P) int32 -- input / output row of every (offset, output site) with a neighbour, grouped by offset,
         ascending output row inside an offset; items (n_items, 4) int32 {offset, first pair, end pair, 0} of at most
-        mgar_spconv_pair_chunk() pairs; item_start (K + 1) int32."""
+        mgar_spconv_pair_chunk() pairs, item_start (K + 1) int32 and the item count for the weight gradient; a finer cut of the
+        same pairs and its item_start as a host array for the per-offset launches of the forward / data gradient."""
         if self._pairs is None:
             mask_t = (self.nbr >= 0).t().contiguous()                            # (K, No)
             counts = mask_t.sum(1).tolist()                                      # one host synchronisation per rulebook
@@ -96,15 +105,27 @@ class Rulebook:
             pair_o = ko[:, 1].int().contiguous()
             pair_i = self.nbr.t()[mask_t].contiguous()
             chunk = L.raw("mgar_spconv_pair_chunk")
-            items, item_start, at = [], [0], 0
-            for k, n in enumerate(counts):
-                for b in range(0, n, chunk):
-                    items.append((k, at + b, at + min(b + chunk, n), 0))
-                at += n
-                item_start.append(len(items))
             dev = self.nbr.device
-            items_t = torch.tensor(items if items else [(0, 0, 0, 0)], dtype=torch.int32).view(-1, 4).to(dev)
-            self._pairs = (pair_i, pair_o, items_t, torch.tensor(item_start, dtype=torch.int32, device=dev), len(items))
+
+            def cut(chunk_of):
+                import numpy as np
+                rows, item_start, at = [], [0], 0
+                for k, n in enumerate(counts):
+                    if n:
+                        c = chunk_of(n)
+                        b = np.arange(0, n, c, dtype=np.int64)
+                        rows.append(np.stack([np.full_like(b, k), at + b, at + np.minimum(b + c, n), np.zeros_like(b)], 1))
+                    at += n
+                    item_start.append(item_start[-1] + (len(rows[-1]) if n else 0))
+                arr = np.concatenate(rows, 0).astype(np.int32) if rows else np.zeros((1, 4), np.int32)
+                return torch.from_numpy(arr).to(dev), item_start, item_start[-1]
+            # weight gradient: all offsets in one launch, long items (few partials).  forward / data gradient: one launch per
+            # offset, so an offset's pairs are cut finely enough to fill the chip (~1 024 workgroups per launch)
+            items_dw, start_dw, n_dw = cut(lambda n: chunk)
+            items_fw, start_fw, _ = cut(lambda n: min(chunk, max(64, -(-n // (1024 * 64)) * 64)))
+            import ctypes
+            self._pairs = (pair_i, pair_o, items_dw, torch.tensor(start_dw, dtype=torch.int32, device=dev), n_dw,
+                           items_fw, (ctypes.c_int * len(start_fw))(*start_fw))
         return self._pairs
 
     def _output_sites(self, geom):
@@ -132,6 +153,23 @@ def _gather_gemm(n_out, k, cin, cout, feats, nbr, w, flip):
     return out
 
 
+def _pairs_gemm(rb, n_dst, src_feats, w, transpose):
+    """dst (n_dst, Cd) = sum_k over the pairs of offset k of src[.] . w[k] (csrc/sparse_conv.hip, spconv_pairs_gemm_kernel).
+    transpose=False: forward (input rows -> output rows, w (K, Cin, Cout)); True: data gradient (dout rows -> input rows, w
+    (K, Cout, Cin) = W_k^T)."""
+    import ctypes
+    pair_i, pair_o, _, _, _, items, start_host = rb.pairs()
+    k, cs, cd = w.shape
+    dst = torch.zeros((n_dst, cd), dtype=torch.float32, device=src_feats.device)
+    ps, pd = (pair_o, pair_i) if transpose else (pair_i, pair_o)
+    L.call("mgar_spconv_pairs_gemm", k, cs, cd, L.fptr(src_feats), L.iptr(ps), L.iptr(pd), L.iptr(items),
+           ctypes.cast(start_host, ctypes.c_void_p), L.fptr(w), L.fptr(dst), L.stream_of(src_feats))
+    return dst
+
+
+PAIRS_FORWARD = True     # forward / data gradient over pair lists (False: the table-driven gather-GEMM)
+
+
 class _SparseConv(Function):
     """out (No, Cout) = sum_k feats[nbr[:, k]] @ w[k]  with w (K, Cin, Cout)."""
 
@@ -139,7 +177,10 @@ class _SparseConv(Function):
     def forward(ctx, feats, w, rb):
         feats, w = feats.contiguous().float(), w.contiguous().float()
         k, cin, cout = w.shape
-        out = _gather_gemm(rb.nbr.shape[0], k, cin, cout, feats, rb.nbr, w, 0)
+        if PAIRS_FORWARD and _pow2(cin) and max(cin, cout) <= 128:
+            out = _pairs_gemm(rb, rb.nbr.shape[0], feats, w, False)
+        else:
+            out = _gather_gemm(rb.nbr.shape[0], k, cin, cout, feats, rb.nbr, w, 0)
         ctx.save_for_backward(feats, w)
         ctx.rb = rb
         return out
@@ -154,11 +195,13 @@ class _SparseConv(Function):
         dfeats = dw = None
         if ctx.needs_input_grad[0]:
             wt = w.transpose(1, 2).contiguous()                                   # (K, Cout, Cin)
-            table = rb.nbr if rb.subm else rb.inv
-            dfeats = _gather_gemm(feats.shape[0], k, cout, cin, dout, table, wt, 1 if rb.subm else 0)
+            if PAIRS_FORWARD and _pow2(cout) and max(cin, cout) <= 128:
+                dfeats = _pairs_gemm(rb, feats.shape[0], dout, wt, True)
+            else:
+                dfeats = _gather_gemm(feats.shape[0], k, cout, cin, dout, rb.nbr if rb.subm else rb.inverse_table(), wt, 1 if rb.subm else 0)
         if ctx.needs_input_grad[1] and _pow2(cin) and _pow2(cout) and max(cin, cout) <= 128:
             # pair lists: no work on sites without a neighbour under the offset, tiles software-pipelined (csrc/sparse_conv.hip)
-            pair_i, pair_o, items, item_start, n_items = rb.pairs()
+            pair_i, pair_o, items, item_start, n_items = rb.pairs()[:5]
             part = torch.empty((max(n_items, 1), cin, cout), dtype=torch.float32, device=feats.device)
             dw = torch.empty((k, cin, cout), dtype=torch.float32, device=feats.device)
             L.call("mgar_spconv_pairs_dw", n_items, k, cin, cout, L.fptr(feats), L.fptr(dout), L.iptr(pair_i), L.iptr(pair_o), L.iptr(items),

@@ -170,3 +170,31 @@ def test_voxel_query_through_hash_table_equals_dense_table(oracle):
         # the oracle leaves the slots of an empty row (beyond its -1 marker) at the caller's zeros, as the kernels do
         assert np.array_equal(a.cpu().numpy(), want)
         assert (a[:, 0] >= 0).sum() > 50 and (a[:, 0] < 0).sum() > 5
+
+
+@pytest.mark.parametrize("subm,kernel,stride,padding,cin,cout", [(True, 3, 1, 1, 16, 32), (False, 3, 2, 1, 32, 64), (False, (3, 1, 1), (2, 1, 1), 0, 64, 128),
+                                                                  (True, 3, 1, 1, 4, 16)])
+def test_pair_list_kernels_equal_the_table_driven_ones(subm, kernel, stride, padding, cin, cout, monkeypatch):
+    """Forward, data gradient and weight gradient over the compacted pair lists (one launch per kernel offset, no atomics)
+    against the table-driven gather-GEMM / chunked dW on a few thousand sites; twice the same result (fixed summation order)."""
+    from multimodal_gar_amd import sparse_ops
+    shape, batch = [12, 40, 44], 3
+    idx = sparse_sites(11, batch, tuple(shape), 0.10).cuda()
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(idx.shape[0], cin, generator=g).cuda()
+    kk = sparse_ops._triple(kernel)
+    w = (torch.randn(cout, *kk, cin, generator=g) / (cin * kk[0] * kk[1] * kk[2]) ** 0.5).cuda()
+    res = []
+    for pairs in (True, False, True):
+        monkeypatch.setattr(sparse_ops, "PAIRS_FORWARD", pairs)
+        monkeypatch.setattr(sparse_ops, "_pow2", (lambda v: v >= 1 and (v & (v - 1)) == 0) if pairs else (lambda v: False))
+        f, ww = feats.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        out, oidx, _ = sparse_ops.sparse_conv3d(f, idx, shape, batch, ww, kernel, stride, padding, subm, {}, "k")
+        cot = torch.linspace(-1, 1, out.numel(), device="cuda").view(out.shape)
+        (out * cot).sum().backward()
+        res.append((out.detach(), f.grad, ww.grad, oidx))
+    assert idx.shape[0] > 3000 and torch.equal(res[0][3], res[1][3])
+    for a, b, what in zip(res[0][:3], res[1][:3], ("out", "d features", "d weight")):
+        assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-6), what
+    for a, b in zip(res[0][:3], res[2][:3]):
+        assert torch.equal(a, b)
