@@ -157,6 +157,123 @@ __global__ void stem_pack_weights_kernel(const float *__restrict__ w, float *__r
     wp[e] = v;
 }
 
+// ---- bf16 payloads: the same convolution on the bf16 MFMA -------------------------------------------------------------------
+// (configurations c2 / c5: feature payloads AND GEMM operands bf16, fp32 accumulation.)  v_mfma_f32_32x32x16_bf16 takes 8
+// consecutive k per lane and half-wave: with k ordered (kh, kw) and kw padded 7 -> 8, a lane's B fragment is 8 CONSECUTIVE input
+// columns 2 wo .. 2 wo + 7 of input row 2 ho + kh -- four aligned 4-byte LDS reads of the bf16 patch, no de-interleaving -- and
+// its A fragment 16 contiguous bytes of the weights packed [k-step][co][kh parity][kw].  A (kt, c_in) slab is 4 k-steps (kh pairs
+// (0,1) (2,3) (4,5) (6,-)) x 4 accumulators = 16 MFMAs per wave instead of 100 fp32 ones; same tile, same double-buffered
+// pipeline, same epilogue.  Weights are rounded to bf16 once per call (what a bf16 convolution does).
+typedef __bf16 __attribute__((ext_vector_type(8))) bf16x8;
+constexpr int SCB_COLS = 72;                                              // patch row pitch in bf16 (69 columns + pad)
+constexpr int SCB_IN_HALVES = SCV_IH * SCB_COLS;                          // 1512
+constexpr int SCB_W_HALVES = 4 * SCV_COUT * 16;                           // 4096 per slab: [step][co][h][8]
+
+__global__ __launch_bounds__(256, 2) void stem_conv3d_bf16_kernel(const bf16_t *__restrict__ x, const uint4 *__restrict__ wp, StemArgs a,
+                                                                  bf16_t *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_in[2][SCB_IN_HALVES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_w[2][SCB_W_HALVES];
+    const int tiles_w = (a.Wo + SCV_TW - 1) / SCV_TW;
+    const int bx = blockIdx.x % tiles_w, by = blockIdx.x / tiles_w;
+    const int to = blockIdx.y, n = blockIdx.z;
+    const int wo0 = bx * SCV_TW, ho0 = by * SCV_TH;
+    const int hbase = SCV_S * ho0 - a.ph, wbase = SCV_S * wo0 - a.pw;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int t0 = SCV_S * to - a.pt;
+    const int kt_lo = max(0, -t0), kt_hi = min(SCV_K, a.T - t0);
+    const int nslab = max(0, kt_hi - kt_lo) * SCV_CIN;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+    for (int e = threadIdx.x; e < 2 * SCB_IN_HALVES; e += 256) s_in[0][e] = 0;   // the pad columns of both buffers stay zero
+
+    uint16_t pin[SCV_IN_PER_THREAD];
+    uint4 pw4[2];
+    auto fetch = [&](int slab) {
+        const int kt = kt_lo + slab / SCV_CIN, c = slab % SCV_CIN;
+        const bf16_t *plane = x + (((size_t)n * SCV_CIN + c) * a.T + (t0 + kt)) * a.H * a.W;
+#pragma unroll
+        for (int u = 0; u < SCV_IN_PER_THREAD; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int ir = e / SCV_IW, ic = e - ir * SCV_IW;
+            const int hh = hbase + ir, ww = wbase + ic;
+            pin[u] = (e < SCV_IH * SCV_IW && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? plane[(size_t)hh * a.W + ww].bits : (uint16_t)0;
+        }
+        const uint4 *wsrc = wp + (size_t)(kt * SCV_CIN + c) * (SCB_W_HALVES / 8);
+        pw4[0] = wsrc[threadIdx.x];
+        pw4[1] = wsrc[threadIdx.x + 256];
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < SCV_IN_PER_THREAD; ++u) {
+            const int e = threadIdx.x + u * 256;
+            const int ir = e / SCV_IW, ic = e - ir * SCV_IW;
+            if (e < SCV_IH * SCV_IW) s_in[buf][ir * SCB_COLS + ic] = pin[u];
+        }
+        reinterpret_cast<uint4 *>(s_w[buf])[threadIdx.x] = pw4[0];
+        reinterpret_cast<uint4 *>(s_w[buf])[threadIdx.x + 256] = pw4[1];
+    };
+    __syncthreads();
+    if (nslab > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int slab = 0; slab < nslab; ++slab) {
+        const int buf = slab & 1;
+        if (slab + 1 < nslab) fetch(slab + 1);
+        const uint16_t *ti = s_in[buf], *tw = s_w[buf];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kh = min(2 * st + h, SCV_K - 1);                     // kh = 7 carries zero weights: any valid row
+            const uint4 wa0 = *reinterpret_cast<const uint4 *>(tw + ((st * SCV_COUT + l) * 2 + h) * 8);
+            const uint4 wa1 = *reinterpret_cast<const uint4 *>(tw + ((st * SCV_COUT + 32 + l) * 2 + h) * 8);
+            const uint32_t *r0 = reinterpret_cast<const uint32_t *>(ti + (SCV_S * (2 * wave + 0) + kh) * SCB_COLS) + l;
+            const uint32_t *r1 = reinterpret_cast<const uint32_t *>(ti + (SCV_S * (2 * wave + 1) + kh) * SCB_COLS) + l;
+            const uint4 b0 = make_uint4(r0[0], r0[1], r0[2], r0[3]);
+            const uint4 b1 = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+            const bf16x8 fa0 = __builtin_bit_cast(bf16x8, wa0), fa1 = __builtin_bit_cast(bf16x8, wa1);
+            const bf16x8 fb0 = __builtin_bit_cast(bf16x8, b0), fb1 = __builtin_bit_cast(bf16x8, b1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1, fb1, acc[1][1], 0, 0, 0);
+        }
+        if (slab + 1 < nslab) stash(buf ^ 1);
+        __syncthreads();
+    }
+    const int wo = wo0 + l;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int ho = ho0 + 2 * wave + nb;
+        if (ho >= a.Ho || wo >= a.Wo) continue;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                Payload<bf16_t>::st(y + ((((size_t)n * SCV_COUT + co) * a.To + to) * a.Ho + ho) * a.Wo + wo, acc[mb][nb][r]);
+            }
+    }
+}
+
+// (64, 3, 7, 7, 7) fp32 -> bf16 [kt][c][step 4][co 64][h 2][kw 8]: kh = 2 step + h, zero for kh = 7 or kw = 7
+__global__ void stem_pack_weights_bf16_kernel(const float *__restrict__ w, uint16_t *__restrict__ wp) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= SCV_K * SCV_CIN * SCB_W_HALVES) return;
+    const int kw = e & 7, hh = (e >> 3) & 1, co = (e >> 4) % SCV_COUT, st = (e / (16 * SCV_COUT)) & 3;
+    const int c = (e / SCB_W_HALVES) % SCV_CIN, kt = e / (SCB_W_HALVES * SCV_CIN);
+    const int kh = 2 * st + hh;
+    float v = 0.f;
+    if (kh < SCV_K && kw < SCV_K) v = w[((((size_t)co * SCV_CIN + c) * SCV_K + kt) * SCV_K + kh) * SCV_K + kw];
+    wp[e] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+}
+
 template <typename T>
 static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *w, float *w_packed, T *y, void *stream) {
     MGAR_REQUIRE(N >= 0 && Tn > 0 && H > 0 && W > 0, "stem_conv3d_fwd: bad sizes");
@@ -169,9 +286,18 @@ static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *
     StemArgs a{N, Tn, H, W, (Tn + 1) / 2, (H + 1) / 2, (W + 1) / 2, front(Tn), front(H), front(W)};
     MGAR_REQUIRE(a.To <= 65535 && N <= 65535, "stem_conv3d_fwd: T or N too large");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SCV_W_FLOATS, 256)), dim3(256), 0, st, w, w_packed);
     const int tiles = ((a.Wo + SCV_TW - 1) / SCV_TW) * ((a.Ho + SCV_TH - 1) / SCV_TH);
     const double outs = (double)N * a.To * a.Ho * a.Wo;
+    if (Payload<T>::is_bf16) {                                     // bf16 payloads: operands bf16 on the bf16 MFMA
+        hipLaunchKernelGGL(stem_pack_weights_bf16_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SCB_W_HALVES, 256)), dim3(256), 0, st, w,
+                           reinterpret_cast<uint16_t *>(w_packed));
+        KtScope kt(KT_STEM_CONV, st, (double)sizeof(T) * ((double)N * SCV_CIN * Tn * H * W + outs * SCV_COUT),
+                   2.0 * outs * SCV_COUT * SCV_CIN * SCV_K * SCV_K * SCV_K);
+        hipLaunchKernelGGL(stem_conv3d_bf16_kernel, dim3(tiles, a.To, N), dim3(256), 0, st, reinterpret_cast<const bf16_t *>(x),
+                           reinterpret_cast<const uint4 *>(w_packed), a, reinterpret_cast<bf16_t *>(y));
+        return check_launch("stem_conv3d_fwd: launch failed");
+    }
+    hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SCV_W_FLOATS, 256)), dim3(256), 0, st, w, w_packed);
     {
         KtScope kt(KT_STEM_CONV, st, (double)sizeof(T) * ((double)N * SCV_CIN * Tn * H * W + outs * SCV_COUT),
                    2.0 * outs * SCV_COUT * SCV_CIN * SCV_K * SCV_K * SCV_K);

@@ -400,7 +400,8 @@ def test_kernel_timers_bracket_launches():
                                    (8, 2, 64, 96)])
 def test_stem_conv3d_kernel_vs_padded_library_convolution(shape):
     """csrc/stem_conv.hip (I3D Conv3d_1a_7x7: 3 -> 64, 7x7x7, stride 2, TF "same" padding inside the kernel) against
-    F.pad + conv3d in float64, odd / even sizes (front pads 3 vs 2), partial tiles; bf16 payload = rounded fp32 result."""
+    F.pad + conv3d in float64, odd / even sizes (front pads 3 vs 2), partial tiles; bf16 payloads: the bf16-MFMA kernel against the
+    float64 convolution of the bf16-rounded operands, to one bf16 rounding."""
     import torch.nn.functional as F
     from multimodal_gar_amd.model.backbone import Unit3D
     n, t, h, w = shape
@@ -421,6 +422,11 @@ def test_stem_conv3d_kernel_vs_padded_library_convolution(shape):
         lib = u(x)                                           # the library route of the same module
         assert (lib - got).abs().max().item() <= 1e-4 * want.abs().max().item()
         u.stem_kernel = True
+        # bf16 payloads: operands (inputs AND weights) bf16 on the bf16 MFMA, fp32 accumulation, one rounding of the result
         xb = x.to(torch.bfloat16)
         gb = u(xb)
-        assert gb.dtype == torch.bfloat16 and torch.equal(gb, u(xb.float()).to(torch.bfloat16))
+        wb = u.conv3d.weight.to(torch.bfloat16).double()
+        want_b = F.conv3d(F.pad(xb.double(), pads), wb, stride=2)
+        assert gb.dtype == torch.bfloat16 and gb.shape == want.shape
+        err_b = (gb.double() - want_b).abs()
+        assert (err_b <= 2.0 ** -8 * want_b.abs() + 2e-5 * want_b.abs().max()).all(), err_b.max().item()
