@@ -28,6 +28,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak, same guide
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA, same guide
+BF16_MFMA_KERNELS = {"stem_conv3d_kernel"}   # hand-written kernels whose bf16-payload variant multiplies on the bf16 MFMA
 
 
 # BASELINE.json configs that run on one rank.  c3 is the metric's configuration (and c4 = c3 sharded over ranks);
@@ -119,7 +121,7 @@ def pmc_traffic(clips_local):
     return ok, tag
 
 
-def kernel_rooflines(step, batch, frames, n_points, clips_local=None):
+def kernel_rooflines(step, batch, frames, n_points, clips_local=None, precision="fp32"):
     """One extra, instrumented step (eager, ONE stream) -> (rows, accounting).  rows: one roofline dict per hand-written
     kernel (events inside the library, csrc/errors.hip) AND per library op / shape (convolutions and GEMMs with their
     FLOPs against the MFMA peak of their dtype; multimodal_gar_amd/op_timer.py), the largest total time first.
@@ -153,8 +155,10 @@ def kernel_rooflines(step, batch, frames, n_points, clips_local=None):
                "traffic_source": traffic_src if name in traffic else None}
         if name in MFMA_KERNELS:
             tf = flops / ms / 1e9 if ms > 0 else 0.0
-            row.update({"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / VALU_PEAK_TFLOPS,
-                        "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
+            # the I3D stem runs on the bf16 MFMA (2.5 PF dense) when the payloads are bf16; everything else here is exact fp32 MFMA
+            peak = BF16_MFMA_PEAK_TFLOPS if (precision == "bf16" and name in BF16_MFMA_KERNELS) else VALU_PEAK_TFLOPS
+            row.update({"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                        "mfma_dtype": "bf16" if peak == BF16_MFMA_PEAK_TFLOPS else "f32", "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS})
         else:
             row.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
         if name in PAIR_KERNELS and flops:
@@ -347,7 +351,7 @@ def main():
     roof, kernels, cpu, accounting = None, None, None, None
     if not args.no_kernel_timing:
         if rank == 0:
-            kernels, accounting = kernel_rooflines(step, batch, clips_local * args.frames, args.points, clips_local)
+            kernels, accounting = kernel_rooflines(step, batch, clips_local * args.frames, args.points, clips_local, args.precision)
             # the dominant kernel of the WHOLE step (hand-written or library) that has a roofline; and, beside it, the
             # dominant hand-written one (the kernels this repo can tune)
             dom = next(r for r in kernels if "bound" in r and "frac" in r)
