@@ -165,11 +165,12 @@ __global__ void stem_pack_weights_kernel(const float *__restrict__ w, float *__r
 // (0,1) (2,3) (4,5) (6,-)) x 4 accumulators = 16 MFMAs per wave instead of 100 fp32 ones; same tile, same double-buffered
 // pipeline, same epilogue.  Weights are rounded to bf16 once per call (what a bf16 convolution does).
 typedef __bf16 __attribute__((ext_vector_type(8))) bf16x8;
+typedef unsigned int __attribute__((ext_vector_type(4))) u32x4;
 constexpr int SCB_COLS = 72;                                              // patch row pitch in bf16 (69 columns + pad)
 constexpr int SCB_IN_HALVES = SCV_IH * SCB_COLS;                          // 1512
 constexpr int SCB_W_HALVES = 4 * SCV_COUT * 16;                           // 4096 per slab: [step][co][h][8]
 
-__global__ __launch_bounds__(256, 2) void stem_conv3d_bf16_kernel(const bf16_t *__restrict__ x, const uint4 *__restrict__ wp, StemArgs a,
+__global__ __launch_bounds__(256, 2) void stem_conv3d_bf16_kernel(const bf16_t *__restrict__ x, const u32x4 *__restrict__ wp, StemArgs a,
                                                                   bf16_t *__restrict__ y) {
     __shared__ __attribute__((aligned(16))) uint16_t s_in[2][SCB_IN_HALVES];
     __shared__ __attribute__((aligned(16))) uint16_t s_w[2][SCB_W_HALVES];
@@ -192,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void stem_conv3d_bf16_kernel(const bf16_t *
             for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
     for (int e = threadIdx.x; e < 2 * SCB_IN_HALVES; e += 256) s_in[0][e] = 0;   // the pad columns of both buffers stay zero
 
-    uint16_t pin[SCV_IN_PER_THREAD];
-    uint4 pw4[2];
+    uint32_t pin[SCV_IN_PER_THREAD];                      // one bf16 each (kept in 32-bit registers)
+    u32x4 pwa, pwb;
     auto fetch = [&](int slab) {
         const int kt = kt_lo + slab / SCV_CIN, c = slab % SCV_CIN;
         const bf16_t *plane = x + (((size_t)n * SCV_CIN + c) * a.T + (t0 + kt)) * a.H * a.W;
@@ -202,21 +203,21 @@ __global__ __launch_bounds__(256, 2) void stem_conv3d_bf16_kernel(const bf16_t *
             const int e = threadIdx.x + u * 256;
             const int ir = e / SCV_IW, ic = e - ir * SCV_IW;
             const int hh = hbase + ir, ww = wbase + ic;
-            pin[u] = (e < SCV_IH * SCV_IW && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? plane[(size_t)hh * a.W + ww].bits : (uint16_t)0;
+            pin[u] = (e < SCV_IH * SCV_IW && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? (uint32_t)plane[(size_t)hh * a.W + ww].bits : 0u;
         }
-        const uint4 *wsrc = wp + (size_t)(kt * SCV_CIN + c) * (SCB_W_HALVES / 8);
-        pw4[0] = wsrc[threadIdx.x];
-        pw4[1] = wsrc[threadIdx.x + 256];
+        const u32x4 *wsrc = wp + (size_t)(kt * SCV_CIN + c) * (SCB_W_HALVES / 8);
+        pwa = wsrc[threadIdx.x];
+        pwb = wsrc[threadIdx.x + 256];
     };
     auto stash = [&](int buf) {
 #pragma unroll
         for (int u = 0; u < SCV_IN_PER_THREAD; ++u) {
             const int e = threadIdx.x + u * 256;
             const int ir = e / SCV_IW, ic = e - ir * SCV_IW;
-            if (e < SCV_IH * SCV_IW) s_in[buf][ir * SCB_COLS + ic] = pin[u];
+            if (e < SCV_IH * SCV_IW) s_in[buf][ir * SCB_COLS + ic] = (uint16_t)pin[u];
         }
-        reinterpret_cast<uint4 *>(s_w[buf])[threadIdx.x] = pw4[0];
-        reinterpret_cast<uint4 *>(s_w[buf])[threadIdx.x + 256] = pw4[1];
+        reinterpret_cast<u32x4 *>(s_w[buf])[threadIdx.x] = pwa;
+        reinterpret_cast<u32x4 *>(s_w[buf])[threadIdx.x + 256] = pwb;
     };
     __syncthreads();
     if (nslab > 0) {
@@ -231,12 +232,12 @@ __global__ __launch_bounds__(256, 2) void stem_conv3d_bf16_kernel(const bf16_t *
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             const int kh = min(2 * st + h, SCV_K - 1);                     // kh = 7 carries zero weights: any valid row
-            const uint4 wa0 = *reinterpret_cast<const uint4 *>(tw + ((st * SCV_COUT + l) * 2 + h) * 8);
-            const uint4 wa1 = *reinterpret_cast<const uint4 *>(tw + ((st * SCV_COUT + 32 + l) * 2 + h) * 8);
+            const u32x4 wa0 = *reinterpret_cast<const u32x4 *>(tw + ((st * SCV_COUT + l) * 2 + h) * 8);
+            const u32x4 wa1 = *reinterpret_cast<const u32x4 *>(tw + ((st * SCV_COUT + 32 + l) * 2 + h) * 8);
             const uint32_t *r0 = reinterpret_cast<const uint32_t *>(ti + (SCV_S * (2 * wave + 0) + kh) * SCB_COLS) + l;
             const uint32_t *r1 = reinterpret_cast<const uint32_t *>(ti + (SCV_S * (2 * wave + 1) + kh) * SCB_COLS) + l;
-            const uint4 b0 = make_uint4(r0[0], r0[1], r0[2], r0[3]);
-            const uint4 b1 = make_uint4(r1[0], r1[1], r1[2], r1[3]);
+            const u32x4 b0 = {r0[0], r0[1], r0[2], r0[3]};
+            const u32x4 b1 = {r1[0], r1[1], r1[2], r1[3]};
             const bf16x8 fa0 = __builtin_bit_cast(bf16x8, wa0), fa1 = __builtin_bit_cast(bf16x8, wa1);
             const bf16x8 fb0 = __builtin_bit_cast(bf16x8, b0), fb1 = __builtin_bit_cast(bf16x8, b1);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0, fb0, acc[0][0], 0, 0, 0);
@@ -294,7 +295,7 @@ static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *
         KtScope kt(KT_STEM_CONV, st, (double)sizeof(T) * ((double)N * SCV_CIN * Tn * H * W + outs * SCV_COUT),
                    2.0 * outs * SCV_COUT * SCV_CIN * SCV_K * SCV_K * SCV_K);
         hipLaunchKernelGGL(stem_conv3d_bf16_kernel, dim3(tiles, a.To, N), dim3(256), 0, st, reinterpret_cast<const bf16_t *>(x),
-                           reinterpret_cast<const uint4 *>(w_packed), a, reinterpret_cast<bf16_t *>(y));
+                           reinterpret_cast<const u32x4 *>(w_packed), a, reinterpret_cast<bf16_t *>(y));
         return check_launch("stem_conv3d_fwd: launch failed");
     }
     hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SCV_W_FLOATS, 256)), dim3(256), 0, st, w, w_packed);
