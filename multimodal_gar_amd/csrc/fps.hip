@@ -488,6 +488,89 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(FpsArgs A) {
     }
 }
 
+// Clouds of up to 65 536 points (BASELINE config c5): the coordinates still do not fit the register file, but the running
+// minimum distances do -- 64 per lane -- and the coordinate stream can be issued eight points ahead instead of one.  Same
+// scan order, same strict comparison, same tie rule and reduction as fps_stream_kernel (whose loop waits for every load:
+// 24 us per sample at n = 65 536); temp is read once and written back at the end.
+template <int PPT>
+__global__ __launch_bounds__(1024) void fps_stream_reg_kernel(FpsArgs A) {
+    constexpr int NW = 16, UN = PPT > 32 ? 4 : 8;      // coordinate loads in flight per lane (register budget: 128)
+    __shared__ FpsSlot slots[2][16];
+    const int cloud = blockIdx.x;
+    const int start = cloud * A.n_batch, ostart = cloud * A.m_batch;      // batch flavour only (bs = 1024)
+    const int n = A.n_batch, m = A.m_batch, bs_log2 = 10;
+    if (m <= 0 || n <= 0) return;
+    const float *__restrict__ P = A.points + (size_t)start * 3;
+    float *__restrict__ temp = A.temp + start;
+    int *__restrict__ out = A.idx + ostart;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bs = 1 << bs_log2;
+    const int L = (n + bs - 1) >> bs_log2;
+    float t[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + i * 1024;
+        t[i] = k < n ? temp[k] : -1.f;                                    // -1: never larger than `best`
+    }
+    float x1 = P[0], y1 = P[1], z1 = P[2];
+    if (tid == 0) out[0] = 0;
+    for (int j = 1; j < m; ++j) {
+        float best = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
+        int bk = 0;
+        int tv = tid;
+        asm volatile("" : "+v"(tv));       // addresses are recomputed per sample: hoisting all 3 * PPT of them out of this loop spills
+#pragma unroll
+        for (int i0 = 0; i0 < PPT; i0 += UN) {
+            float px[UN], py[UN], pz[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = tv + (i0 + u) * 1024;
+                const bool ok = k < n;
+                px[u] = ok ? P[k * 3 + 0] : 0.f;
+                py[u] = ok ? P[k * 3 + 1] : 0.f;
+                pz[u] = ok ? P[k * 3 + 2] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const int k = tv + (i0 + u) * 1024;
+                const float d = d2_of(px[u] - x1, py[u] - y1, pz[u] - z1);
+                const float d2 = k < n ? vmin(d, t[i0 + u]) : -1.f;
+                t[i0 + u] = d2;
+                if (d2 > best) { best = d2; bk = k; bx = px[u]; by = py[u]; bz = pz[u]; }
+            }
+        }
+        const unsigned prio = (__brev((unsigned)(bk & (bs - 1))) >> (32 - bs_log2)) * (unsigned)L + (unsigned)(bk >> bs_log2);
+        const unsigned long long mykey = ((unsigned long long)ordered_bits(best) << 32) | (unsigned long long)(0xFFFFFFFFu - prio);
+        const unsigned long long wkey = wave_umax64(mykey);
+        FpsSlot *buf = slots[j & 1];
+        if (mykey == wkey) {
+            FpsSlot sl;
+            sl.key_lo = (unsigned)wkey; sl.key_hi = (unsigned)(wkey >> 32);
+            sl.x = bx; sl.y = by; sl.z = bz; sl.k = bk; sl.pad0 = 0; sl.pad1 = 0;
+            buf[wave] = sl;
+        }
+        __syncthreads();
+        const int w = lane & 15;
+        FpsSlot sl = buf[w < NW ? w : 0];
+        unsigned long long skey = ((unsigned long long)sl.key_hi << 32) | sl.key_lo;
+        unsigned long long rkey = row_umax64(skey);
+        const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rkey, 15);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rkey >> 32), 15);
+        const unsigned long long gkey = ((unsigned long long)rhi << 32) | rlo;
+        const int src = __builtin_ctzll(__builtin_amdgcn_ballot_w64(skey == gkey));
+        x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.x), src));
+        y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.y), src));
+        z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.z), src));
+        const int win_k = __builtin_amdgcn_readlane(sl.k, src);
+        if (tid == 0) out[j] = win_k;
+    }
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + i * 1024;
+        if (k < n) temp[k] = t[i];
+    }
+}
+
 template <int T>
 static bool launch_fps_t(int ppt_needed, int nclouds, const FpsArgs &A, hipStream_t st) {
     if (ppt_needed <= 1) hipLaunchKernelGGL((fps_kernel<T, 1>), dim3(nclouds), dim3(T), 0, st, A);
@@ -518,7 +601,9 @@ static int fps_dispatch(int nclouds, int n_max, int bs_log2, const FpsArgs &A, h
     else ok = launch_fps_t<64>(need, nclouds, A, st);
     if (!ok) {
         // does not fit the register file: only possible with bs == 1024 and n_max > 16384
-        hipLaunchKernelGGL(fps_stream_kernel, dim3(nclouds), dim3(1024), 0, st, A);
+        if (!A.stack && n_max <= 32768) hipLaunchKernelGGL(fps_stream_reg_kernel<32>, dim3(nclouds), dim3(1024), 0, st, A);
+        else if (!A.stack && n_max <= 65536) hipLaunchKernelGGL(fps_stream_reg_kernel<64>, dim3(nclouds), dim3(1024), 0, st, A);
+        else hipLaunchKernelGGL(fps_stream_kernel, dim3(nclouds), dim3(1024), 0, st, A);
     }
     return check_launch("fps: launch failed");
 }

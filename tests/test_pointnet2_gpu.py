@@ -169,12 +169,25 @@ def test_fps_pruned_rejects_out_of_range_sizes():
         L.call("mgar_fps_batch_perm", 1, 500, 4, L.fptr(pts), L.fptr(t), L.iptr(perm), L.iptr(idx), L.stream_of(pts))
 
 
-def test_fps_stream_fallback_large_cloud(ops, oracle):
+@pytest.mark.parametrize("frames,n,m", [(1, 20000, 64), (2, 30011, 200), (1, 40000, 96), (2, 65536, 80), (1, 70000, 48)])
+def test_fps_large_clouds(ops, oracle, frames, n, m):
+    """Clouds that do not fit the register-resident kernels: up to 32 768 / 65 536 points the minimum distances stay in registers
+    and only the coordinates stream (fps_stream_reg_kernel<32 / 64>); beyond that everything streams (fps_stream_kernel).
+    The caller's temp buffer holds the final minimum distances, as after the reference's kernel."""
     pb = ops[0]
-    xyz = scene_xyz(99, 1, 20000)
-    got = pb.farthest_point_sample(dev(xyz), 64).cpu().numpy()
-    want, _ = oracle.fps_batch(xyz, 64)
+    xyz = scene_xyz(99 + n, frames, n)
+    got = pb.farthest_point_sample(dev(xyz), m).cpu().numpy()
+    want, _ = oracle.fps_batch(xyz, m)
     np.testing.assert_array_equal(got, want)
+    from multimodal_gar_amd import _lib as L
+    pts = dev(xyz)
+    temp = torch.full((frames, n), 1e10, device="cuda")
+    idx = torch.zeros((frames, m), dtype=torch.int32, device="cuda")
+    L.call("mgar_fps_batch", frames, n, m, L.fptr(pts), L.fptr(temp), L.iptr(idx), L.stream_of(pts))
+    assert np.array_equal(idx.cpu().numpy(), want)
+    sel = torch.from_numpy(xyz)[torch.arange(frames)[:, None], torch.from_numpy(want[:, :m - 1]).long()]     # the last sample updates nothing
+    d = ((torch.from_numpy(xyz)[:, :, None, :] - sel[:, None, :, :]) ** 2).sum(-1).min(2).values
+    assert torch.allclose(temp.cpu(), d, rtol=1e-5, atol=1e-6)
 
 
 def test_fps_stack_ragged(ops, oracle):
