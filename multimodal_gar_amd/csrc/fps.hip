@@ -488,19 +488,25 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(FpsArgs A) {
     }
 }
 
-// Clouds of up to 65 536 points (BASELINE config c5): the coordinates still do not fit the register file, but the running
-// minimum distances do -- 64 per lane -- and the coordinate stream can be issued eight points ahead instead of one.  Same
-// scan order, same strict comparison, same tie rule and reduction as fps_stream_kernel (whose loop waits for every load:
-// 24 us per sample at n = 65 536); temp is read once and written back at the end.
+// Clouds of up to 65 536 points (BASELINE config c5): the coordinates do not fit the register file, but the running minimum
+// distances do (64 per lane).  The coordinates are streamed every sample, as the reference does -- but as fully coalesced
+// 16-byte loads into a double-buffered LDS stage of 4 096 points (the next chunk in flight while the current one is scanned),
+// from which every lane reads its own points (stride 3 words: conflict-free).  fps_stream_kernel's 4-byte loads at a 12-byte
+// lane stride spend 28 us per sample at n = 65 536 in the texture path alone.  Same scan order, strict comparison, tie rule
+// and reduction; temp is read once and written back at the end.  Needs n % 4 == 0 (16-byte aligned clouds).
+constexpr int FS_CHUNK = 4096;                                            // points per LDS stage
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_stream_reg_kernel(FpsArgs A) {
-    constexpr int NW = 16, UN = PPT > 32 ? 4 : 8;      // coordinate loads in flight per lane (register budget: 128)
+    constexpr int NW = 16, NCH = PPT / 4;                                 // chunks of 4 096 points = 4 per lane
     __shared__ FpsSlot slots[2][16];
+    __shared__ __attribute__((aligned(16))) float stage[2][FS_CHUNK * 3];
     const int cloud = blockIdx.x;
     const int start = cloud * A.n_batch, ostart = cloud * A.m_batch;      // batch flavour only (bs = 1024)
     const int n = A.n_batch, m = A.m_batch, bs_log2 = 10;
     if (m <= 0 || n <= 0) return;
     const float *__restrict__ P = A.points + (size_t)start * 3;
+    const float4 *__restrict__ P4 = reinterpret_cast<const float4 *>(P);
+    const int n4 = n * 3 / 4;                                             // float4 words of the cloud
     float *__restrict__ temp = A.temp + start;
     int *__restrict__ out = A.idx + ostart;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -514,29 +520,36 @@ __global__ __launch_bounds__(1024) void fps_stream_reg_kernel(FpsArgs A) {
     }
     float x1 = P[0], y1 = P[1], z1 = P[2];
     if (tid == 0) out[0] = 0;
+    float4 pre[3];                                                        // the chunk in flight: 3 072 float4 over 1 024 lanes
+    int tv = tid;                                                         // re-materialised per sample (see below)
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = c * (FS_CHUNK * 3 / 4) + tv + q * 1024;
+            pre[q] = e < n4 ? P4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
     for (int j = 1; j < m; ++j) {
         float best = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
         int bk = 0;
-        int tv = tid;
-        asm volatile("" : "+v"(tv));       // addresses are recomputed per sample: hoisting all 3 * PPT of them out of this loop spills
+        asm volatile("" : "+v"(tv));       // keeps the 3 * NCH load addresses from being hoisted out of this loop (they would spill)
 #pragma unroll
-        for (int i0 = 0; i0 < PPT; i0 += UN) {
-            float px[UN], py[UN], pz[UN];
+        for (int c = 0; c < NCH; ++c) {
+            float4 *sg = reinterpret_cast<float4 *>(stage[c & 1]);
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int k = tv + (i0 + u) * 1024;
-                const bool ok = k < n;
-                px[u] = ok ? P[k * 3 + 0] : 0.f;
-                py[u] = ok ? P[k * 3 + 1] : 0.f;
-                pz[u] = ok ? P[k * 3 + 2] : 0.f;
-            }
+            for (int q = 0; q < 3; ++q) sg[tid + q * 1024] = pre[q];
+            __syncthreads();                                              // also: every wave is done with the other buffer's previous chunk
+            fetch(c + 1 < NCH ? c + 1 : 0);                              // in flight while this chunk is scanned
+            const float *sf = stage[c & 1];
 #pragma unroll
-            for (int u = 0; u < UN; ++u) {
-                const int k = tv + (i0 + u) * 1024;
-                const float d = d2_of(px[u] - x1, py[u] - y1, pz[u] - z1);
-                const float d2 = k < n ? vmin(d, t[i0 + u]) : -1.f;
-                t[i0 + u] = d2;
-                if (d2 > best) { best = d2; bk = k; bx = px[u]; by = py[u]; bz = pz[u]; }
+            for (int i = 0; i < 4; ++i) {
+                const int k = tid + (4 * c + i) * 1024;
+                const float px = sf[(tid + i * 1024) * 3 + 0], py = sf[(tid + i * 1024) * 3 + 1], pz = sf[(tid + i * 1024) * 3 + 2];
+                const float d = d2_of(px - x1, py - y1, pz - z1);
+                const float d2 = k < n ? vmin(d, t[4 * c + i]) : -1.f;
+                t[4 * c + i] = d2;
+                if (d2 > best) { best = d2; bk = k; bx = px; by = py; bz = pz; }
             }
         }
         const unsigned prio = (__brev((unsigned)(bk & (bs - 1))) >> (32 - bs_log2)) * (unsigned)L + (unsigned)(bk >> bs_log2);
@@ -601,8 +614,10 @@ static int fps_dispatch(int nclouds, int n_max, int bs_log2, const FpsArgs &A, h
     else ok = launch_fps_t<64>(need, nclouds, A, st);
     if (!ok) {
         // does not fit the register file: only possible with bs == 1024 and n_max > 16384
-        if (!A.stack && n_max <= 32768) hipLaunchKernelGGL(fps_stream_reg_kernel<32>, dim3(nclouds), dim3(1024), 0, st, A);
-        else if (!A.stack && n_max <= 65536) hipLaunchKernelGGL(fps_stream_reg_kernel<64>, dim3(nclouds), dim3(1024), 0, st, A);
+        if (!A.stack && n_max <= 32768 && n_max % 4 == 0 && (reinterpret_cast<uintptr_t>(A.points) & 15) == 0)
+            hipLaunchKernelGGL(fps_stream_reg_kernel<32>, dim3(nclouds), dim3(1024), 0, st, A);
+        else if (!A.stack && n_max <= 65536 && n_max % 4 == 0 && (reinterpret_cast<uintptr_t>(A.points) & 15) == 0)
+            hipLaunchKernelGGL(fps_stream_reg_kernel<64>, dim3(nclouds), dim3(1024), 0, st, A);
         else hipLaunchKernelGGL(fps_stream_kernel, dim3(nclouds), dim3(1024), 0, st, A);
     }
     return check_launch("fps: launch failed");
