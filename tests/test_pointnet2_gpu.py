@@ -179,6 +179,11 @@ def test_fps_large_clouds(ops, oracle, frames, n, m):
     got = pb.farthest_point_sample(dev(xyz), m).cpu().numpy()
     want, _ = oracle.fps_batch(xyz, m)
     np.testing.assert_array_equal(got, want)
+    # tie-heavy: points on a coarse integer lattice (many exactly equal distances, duplicates) -- the tie rule decides
+    lat = np.stack([lattice(np.random.default_rng(n + f), (n, 3)) for f in range(frames)])
+    got_l = pb.farthest_point_sample(dev(lat), min(m, 40)).cpu().numpy()
+    want_l, _ = oracle.fps_batch(lat, min(m, 40))
+    np.testing.assert_array_equal(got_l, want_l)
     from multimodal_gar_amd import _lib as L
     pts = dev(xyz)
     temp = torch.full((frames, n), 1e10, device="cuda")
