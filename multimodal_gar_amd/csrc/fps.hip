@@ -490,73 +490,69 @@ __global__ __launch_bounds__(1024) void fps_stream_kernel(FpsArgs A) {
 
 // Clouds of up to 65 536 points (BASELINE config c5): the coordinates do not fit the register file, but the running minimum
 // distances do (64 per lane).  The coordinates are streamed every sample, as the reference does -- but as fully coalesced
-// 16-byte loads: a lane owns groups of FOUR CONSECUTIVE points (three float4 = 48 contiguous bytes), the next group in flight
-// while the current one is scanned; no LDS, no barrier inside the scan.  (fps_stream_kernel's 4-byte loads at a 12-byte lane
-// stride spend 28 us per sample at n = 65 536 in the texture path alone; staging through LDS got 15 us; this one 8.)
-// The winner is the maximum of (distance, then the reference's scan priority): with lanes no longer visiting their points in
-// priority order, a tie inside a lane is decided by comparing the priorities explicitly -- the same total order, so the same
-// indices as the oracle.  temp is read once and written back at the end.  Needs n % 4 == 0 (16-byte aligned clouds).
+// 16-byte loads into a double-buffered LDS stage of 4 096 points (the next chunk in flight while the current one is scanned),
+// from which every lane reads its own points (stride 3 words: conflict-free).  fps_stream_kernel's 4-byte loads at a 12-byte
+// lane stride spend 28 us per sample at n = 65 536 in the texture path alone.  Same scan order, strict comparison, tie rule
+// and reduction; temp is read once and written back at the end.  Needs n % 4 == 0 (16-byte aligned clouds).
+constexpr int FS_CHUNK = 4096;                                            // points per LDS stage
 template <int PPT>
 __global__ __launch_bounds__(1024) void fps_stream_reg_kernel(FpsArgs A) {
-    constexpr int NW = 16, NG = PPT / 4;                                  // groups of 4 points per lane
+    constexpr int NW = 16, NCH = PPT / 4;                                 // chunks of 4 096 points = 4 per lane
     __shared__ FpsSlot slots[2][16];
+    __shared__ __attribute__((aligned(16))) float stage[2][FS_CHUNK * 3];
     const int cloud = blockIdx.x;
     const int start = cloud * A.n_batch, ostart = cloud * A.m_batch;      // batch flavour only (bs = 1024)
     const int n = A.n_batch, m = A.m_batch, bs_log2 = 10;
     if (m <= 0 || n <= 0) return;
     const float *__restrict__ P = A.points + (size_t)start * 3;
     const float4 *__restrict__ P4 = reinterpret_cast<const float4 *>(P);
-    float4 *__restrict__ temp4 = reinterpret_cast<float4 *>(A.temp + start);
-    const int ngroups = n / 4;                                            // n % 4 == 0
+    const int n4 = n * 3 / 4;                                             // float4 words of the cloud
+    float *__restrict__ temp = A.temp + start;
     int *__restrict__ out = A.idx + ostart;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bs = 1 << bs_log2;
     const int L = (n + bs - 1) >> bs_log2;
-    auto prio_of = [&](int k) { return (__brev((unsigned)(k & (bs - 1))) >> (32 - bs_log2)) * (unsigned)L + (unsigned)(k >> bs_log2); };
     float t[PPT];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int e = tid + g * 1024;
-        const float4 v = e < ngroups ? temp4[e] : make_float4(-1.f, -1.f, -1.f, -1.f);   // -1: never larger than `best`
-        t[4 * g] = v.x; t[4 * g + 1] = v.y; t[4 * g + 2] = v.z; t[4 * g + 3] = v.w;
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + i * 1024;
+        t[i] = k < n ? temp[k] : -1.f;                                    // -1: never larger than `best`
     }
     float x1 = P[0], y1 = P[1], z1 = P[2];
     if (tid == 0) out[0] = 0;
+    float4 pre[3];                                                        // the chunk in flight: 3 072 float4 over 1 024 lanes
     int tv = tid;                                                         // re-materialised per sample (see below)
+    auto fetch = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = c * (FS_CHUNK * 3 / 4) + tv + q * 1024;
+            pre[q] = e < n4 ? P4[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
     for (int j = 1; j < m; ++j) {
         float best = -1.f, bx = 0.f, by = 0.f, bz = 0.f;
         int bk = 0;
-        asm volatile("" : "+v"(tv));       // keeps the load addresses from being hoisted out of this loop (they would spill)
-        float4 c0, c1, c2, n0, n1, n2;
-        {
-            const int e = tv;
-            const bool ok = e < ngroups;
-            c0 = ok ? P4[3 * e] : make_float4(0.f, 0.f, 0.f, 0.f);
-            c1 = ok ? P4[3 * e + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            c2 = ok ? P4[3 * e + 2] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        asm volatile("" : "+v"(tv));       // keeps the 3 * NCH load addresses from being hoisted out of this loop (they would spill)
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {                                             // the next group: in flight while this one is scanned
-                const int e = tv + (g + 1) * 1024;
-                const bool ok = e < ngroups;
-                n0 = ok ? P4[3 * e] : make_float4(0.f, 0.f, 0.f, 0.f);
-                n1 = ok ? P4[3 * e + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-                n2 = ok ? P4[3 * e + 2] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            const int k0 = 4 * (tv + g * 1024);
-            const bool live = k0 < n;
-            const float px[4] = {c0.x, c0.w, c1.z, c2.y}, py[4] = {c0.y, c1.x, c1.w, c2.z}, pz[4] = {c0.z, c1.y, c2.x, c2.w};
+        for (int c = 0; c < NCH; ++c) {
+            float4 *sg = reinterpret_cast<float4 *>(stage[c & 1]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) sg[tid + q * 1024] = pre[q];
+            __syncthreads();                                              // also: every wave is done with the other buffer's previous chunk
+            fetch(c + 1 < NCH ? c + 1 : 0);                              // in flight while this chunk is scanned
+            const float *sf = stage[c & 1];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float d = d2_of(px[i] - x1, py[i] - y1, pz[i] - z1);
-                const float d2 = live ? vmin(d, t[4 * g + i]) : -1.f;
-                t[4 * g + i] = d2;
-                if (d2 >= best && (d2 > best || prio_of(k0 + i) < prio_of(bk))) { best = d2; bk = k0 + i; bx = px[i]; by = py[i]; bz = pz[i]; }
+                const int k = tid + (4 * c + i) * 1024;
+                const float px = sf[(tid + i * 1024) * 3 + 0], py = sf[(tid + i * 1024) * 3 + 1], pz = sf[(tid + i * 1024) * 3 + 2];
+                const float d = d2_of(px - x1, py - y1, pz - z1);
+                const float d2 = k < n ? vmin(d, t[4 * c + i]) : -1.f;
+                t[4 * c + i] = d2;
+                if (d2 > best) { best = d2; bk = k; bx = px; by = py; bz = pz; }
             }
-            c0 = n0; c1 = n1; c2 = n2;
         }
-        const unsigned prio = prio_of(bk);
+        const unsigned prio = (__brev((unsigned)(bk & (bs - 1))) >> (32 - bs_log2)) * (unsigned)L + (unsigned)(bk >> bs_log2);
         const unsigned long long mykey = ((unsigned long long)ordered_bits(best) << 32) | (unsigned long long)(0xFFFFFFFFu - prio);
         const unsigned long long wkey = wave_umax64(mykey);
         FpsSlot *buf = slots[j & 1];
@@ -582,9 +578,9 @@ __global__ __launch_bounds__(1024) void fps_stream_reg_kernel(FpsArgs A) {
         if (tid == 0) out[j] = win_k;
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int e = tid + g * 1024;
-        if (e < ngroups) temp4[e] = make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + i * 1024;
+        if (k < n) temp[k] = t[i];
     }
 }
 
