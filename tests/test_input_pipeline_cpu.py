@@ -246,3 +246,23 @@ def test_collate_batch_and_torch_dataloader(tmp_path):
     rb = raw.collate_batch([raw[0], raw[1]])
     assert isinstance(rb, RawClipBatch) and len(rb) == 2 and rb.frames_u8.shape == (2, 3, 24, 188, 3) and rb.frames_u8.dtype == torch.uint8
     assert rb.upper[0].shape == (700, 4) and rb.lower[1].shape == (500, 4) and rb.src_fid == [4, 5]
+
+
+def test_loader_shards_across_two_ranks(tmp_path):
+    """The clip index space splits over ranks with torch's DistributedSampler (one process per GPU, no data-path collective):
+    disjoint, together complete, and every rank's batches collate."""
+    from torch.utils.data.distributed import DistributedSampler
+    from multimodal_gar_amd.dataloader import JRDB_act
+    root, _ = jrdb_tree.make_tree(tmp_path)
+    ds = JRDB_act(jrdb_tree.loader_config(), root, True, jrdb_tree.NUM_ACTIONS, False)
+    seen = []
+    for rank in range(2):
+        sampler = DistributedSampler(ds, num_replicas=2, rank=rank, shuffle=False)
+        loader = torch.utils.data.DataLoader(ds, batch_size=2, sampler=sampler, collate_fn=ds.collate_batch)
+        keys = []
+        for batch in loader:
+            assert batch[0].shape[1:] == (3, 3, 36, 64) and batch[11]["batch_size"] == batch[0].shape[0]
+            keys += [(int(s), int(f)) for s, f in zip(batch[7][:, 0, 0].tolist(), batch[2])]
+        seen.append(keys)
+    assert len(seen[0]) == len(seen[1]) == 4 and not set(seen[0]) & set(seen[1])
+    assert set(seen[0]) | set(seen[1]) == set(ds.frames)
