@@ -167,7 +167,8 @@ def _pairs_gemm(rb, n_dst, src_feats, w, transpose):
     return dst
 
 
-PAIRS_FORWARD = True     # forward / data gradient over pair lists (False: the table-driven gather-GEMM)
+PAIRS_FORWARD = False    # forward over pair lists (False: the table-driven, output-stationary gather-GEMM -- no read-modify-write)
+PAIRS_DGRAD = True       # data gradient over pair lists (no inverse table)
 
 
 class _SparseConv(Function):
@@ -195,7 +196,7 @@ class _SparseConv(Function):
         dfeats = dw = None
         if ctx.needs_input_grad[0]:
             wt = w.transpose(1, 2).contiguous()                                   # (K, Cout, Cin)
-            if PAIRS_FORWARD and _pow2(cout) and max(cin, cout) <= 128:
+            if PAIRS_DGRAD and _pow2(cout) and max(cin, cout) <= 128:
                 dfeats = _pairs_gemm(rb, feats.shape[0], dout, wt, True)
             else:
                 dfeats = _gather_gemm(feats.shape[0], k, cout, cin, dout, rb.nbr if rb.subm else rb.inverse_table(), wt, 1 if rb.subm else 0)

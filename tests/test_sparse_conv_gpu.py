@@ -187,6 +187,7 @@ def test_pair_list_kernels_equal_the_table_driven_ones(subm, kernel, stride, pad
     res = []
     for pairs in (True, False, True):
         monkeypatch.setattr(sparse_ops, "PAIRS_FORWARD", pairs)
+        monkeypatch.setattr(sparse_ops, "PAIRS_DGRAD", pairs)
         monkeypatch.setattr(sparse_ops, "_pow2", (lambda v: v >= 1 and (v & (v - 1)) == 0) if pairs else (lambda v: False))
         f, ww = feats.clone().requires_grad_(True), w.clone().requires_grad_(True)
         out, oidx, _ = sparse_ops.sparse_conv3d(f, idx, shape, batch, ww, kernel, stride, padding, subm, {}, "k")
