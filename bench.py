@@ -22,9 +22,16 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-import multimodal_gar_amd  # noqa: E402,F401  -- points MIOPEN_USER_DB_PATH at a scratch copy of the shipped find-db before MIOpen starts
+torch = None   # imported by _import_torch(): `bench.py --gpus N` must be able to start its ranks before torch / the package load
 
-import torch  # noqa: E402
+
+def _import_torch():
+    global torch
+    import multimodal_gar_amd  # noqa: F401  -- points MIOPEN_USER_DB_PATH at a scratch copy of the shipped find-db before MIOpen starts
+    import torch as _torch
+    torch = _torch
+    return torch
+
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak, same guide
@@ -81,6 +88,9 @@ def parse():
                     help="eager DistributedDataParallel (bucketed all-reduce overlapped with backward) instead of one flattened "
                          "gradient all-reduce after the backward; implies --no-graph (DDP hooks cannot be captured)")
     ap.add_argument("--phases", action="store_true", help="print a synchronised per-phase timing of one step")
+    ap.add_argument("--kernels-out", default=None,
+                    help="where the per-kernel roofline table of the instrumented step is written (default: "
+                         "gpurun_out/bench_kernels_<config>_<route>_<N>gpu_<clips>clips.json; the stdout line only names it)")
     args = ap.parse_args()
     for k, v in CONFIGS[args.config].items():
         if getattr(args, k) is None:
@@ -121,31 +131,51 @@ def pmc_traffic(clips_local):
     return ok, tag
 
 
-def kernel_rooflines(step, batch, frames, n_points, clips_local=None, precision="fp32"):
-    """One extra, instrumented step (eager, ONE stream) -> (rows, accounting).  rows: one roofline dict per hand-written
-    kernel (events inside the library, csrc/errors.hip) AND per library op / shape (convolutions and GEMMs with their
-    FLOPs against the MFMA peak of their dtype; multimodal_gar_amd/op_timer.py), the largest total time first.
-    accounting: where the whole step goes, by class."""
-    from multimodal_gar_amd import _lib as L
-    from multimodal_gar_amd.op_timer import AtenOpTimer
-    # one stream for this step: with the RGB branch on its side stream two kernels share the chip and the time
-    # between a kernel's two events is no longer the time that kernel needs
-    overlap, step.module.overlap_branches = step.module.overlap_branches, False
-    # one plain eager step first: the timed steps replayed a graph (private memory pool) and capture()'s warm-up ran on a
-    # side stream, so this stream's caching-allocator pool is cold -- without this every large allocation of the
-    # instrumented step would be a synchronous hipMalloc sitting between an op's two events
-    step.run_eager(batch)
-    torch.cuda.synchronize()
-    L.kernel_timers(enable=True)
-    L.kernel_timers()                       # drop anything recorded so far
-    t0 = time.perf_counter()
-    with AtenOpTimer() as lib_ops:
-        step.run_eager(batch)
+def _sync():
+    if torch.cuda.is_available():
         torch.cuda.synchronize()
-    step_ms = (time.perf_counter() - t0) * 1e3
-    L.kernel_timers(enable=False)
-    step.module.overlap_branches = overlap
-    table = L.kernel_timers()
+
+
+def extra_steps(step, batch, instrument):
+    """The two extra eager steps every rank issues after the timed region -- the SAME number of steps (hence of gradient
+    exchanges) on every rank; only what surrounds the second one differs: `instrument` (rank 0) brackets it with the
+    library's kernel timers and the aten-op timer.  -> (kernel table, AtenOpTimer, wall ms) or None.
+
+    One stream for these steps: with the RGB branch on its side stream two kernels share the chip and the time between a
+    kernel's two events is no longer the time that kernel needs.  The first, plain step is there because the timed steps
+    replayed a graph (private memory pool) and capture()'s warm-up ran on a side stream, so this stream's caching-allocator
+    pool is cold -- without it every large allocation of the instrumented step would be a synchronous hipMalloc sitting
+    between an op's two events."""
+    overlap, step.module.overlap_branches = step.module.overlap_branches, False
+    try:
+        step.run_eager(batch)
+        _sync()
+        if not instrument:
+            step.run_eager(batch)
+            _sync()
+            return None
+        from multimodal_gar_amd import _lib as L
+        from multimodal_gar_amd.op_timer import AtenOpTimer
+        L.kernel_timers(enable=True)
+        L.kernel_timers()                       # drop anything recorded so far
+        t0 = time.perf_counter()
+        try:
+            with AtenOpTimer() as lib_ops:
+                step.run_eager(batch)
+                _sync()
+        finally:
+            L.kernel_timers(enable=False)
+        step_ms = (time.perf_counter() - t0) * 1e3
+        return L.kernel_timers(), lib_ops, step_ms
+    finally:
+        step.module.overlap_branches = overlap
+
+
+def kernel_rooflines(table, lib_ops, step_ms, clips_local=None, precision="fp32"):
+    """The instrumented step's records -> (rows, accounting).  rows: one roofline dict per hand-written kernel (events
+    inside the library, csrc/errors.hip) AND per library op / shape (convolutions and GEMMs with their FLOPs against the
+    MFMA peak of their dtype; multimodal_gar_amd/op_timer.py), the largest total time first.  accounting: where the whole
+    step goes, by class."""
     traffic, traffic_src = pmc_traffic(clips_local)
     res = []
     for name, (ms, launches, nbytes, flops) in table.items():
@@ -153,6 +183,8 @@ def kernel_rooflines(step, batch, frames, n_points, clips_local=None, precision=
         row = {"kernel": name, "class": "hand_written", "launches_per_step": launches, "ms_per_step": ms, "avg_launch_ms": ms / launches,
                "algorithmic_bytes_per_launch": nbytes / launches, "traffic": traffic.get(name),
                "traffic_source": traffic_src if name in traffic else None}
+        if flops:
+            row["flops_per_launch"] = flops / launches
         if name in MFMA_KERNELS:
             tf = flops / ms / 1e9 if ms > 0 else 0.0
             # the I3D stem runs on the bf16 MFMA (2.5 PF dense) when the payloads are bf16; everything else here is exact fp32 MFMA
@@ -177,9 +209,7 @@ def kernel_rooflines(step, batch, frames, n_points, clips_local=None, precision=
     hand = sum(ms for ms, _, _, _ in table.values())
     accounting = {"hand_written_kernels_ms": hand, "library_conv_ms": lib_totals["conv"], "library_gemm_ms": lib_totals["gemm"],
                   "torch_elementwise_copy_reduce_ms": lib_totals["other"],
-                  "sum_ms": hand + sum(lib_totals.values()), "instrumented_step_wall_ms": step_ms,
-                  "note": "one eager single-stream step with events around every kernel / aten op (slower than the timed "
-                          "graph-replayed two-stream steps; its purpose is attribution)"}
+                  "sum_ms": hand + sum(lib_totals.values()), "instrumented_step_wall_ms": step_ms}
     return res, accounting
 
 
@@ -260,21 +290,133 @@ def phase_timing(step, batch):
     return out
 
 
+LINE_LIMIT = 4096   # bytes: the driver keeps a bounded tail of stdout (BENCH_r02: a 22 KB line lost its head and parsed as null)
+ROOF_KEYS = ("kernel", "class", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "ms_per_step",
+             "avg_launch_ms", "algorithmic_bytes_per_launch", "flops_per_launch", "dtype", "mfma_dtype", "valu_frac")
+
+
+def _round(x, digits=5):
+    """Floats to `digits` significant digits, recursively (line size)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    if isinstance(x, dict):
+        return {k: _round(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, digits) for v in x]
+    return x
+
+
+def roofline_entry(kernels):
+    """The `roofline` object of the line: the dominant kernel of the WHOLE step (hand-written or library) that has a
+    roofline, and beside it the dominant hand-written one (the kernels this repo can tune)."""
+    dom = next(r for r in kernels if "bound" in r and "frac" in r)
+    own = next((r for r in kernels if r.get("class") == "hand_written"), None)
+    roof = {k: dom[k] for k in ROOF_KEYS if k in dom}
+    roof.setdefault("traffic", None)
+    if own is not None and own is not dom:
+        roof["dominant_hand_written"] = {k: own[k] for k in ROOF_KEYS if k in own}
+        roof["dominant_hand_written"].setdefault("traffic", None)
+    roof["measured_in"] = ("one eager single-stream step issued after the timed region, HIP events around every kernel / "
+                           "aten op (the timed steps replay a two-stream HIP graph); traffic = committed rocprofv3 --pmc "
+                           "passes (profiles/pmc_hbm_traffic.json), null when not measured for this kernel / batch")
+    return roof
+
+
+def compact_line(line):
+    """-> the ONE stdout line: json.dumps of `line` with floats shortened; asserted below LINE_LIMIT."""
+    text = json.dumps(_round(line), separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:   # cannot happen with the fixed key set; shed the optional parts rather than lose the record
+        slim = dict(line)
+        for k in ("step_accounting",):
+            slim.pop(k, None)
+        if isinstance(slim.get("cpu_baseline"), dict):
+            slim["cpu_baseline"] = {k: v for k, v in slim["cpu_baseline"].items() if k != "sample"} | \
+                {"sample": str(slim["cpu_baseline"].get("sample", ""))[:200]}
+        text = json.dumps(_round(slim, 4), separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, "bench line is %d bytes" % len(text)
+    return text
+
+
+def write_kernel_table(path, kernels, accounting, header):
+    """The per-kernel roofline table (one row per hand-written kernel and per library op / shape) goes to a side file, not
+    into the stdout line."""
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"bench": header, "step_accounting": accounting, "kernels": kernels}, f, indent=1)
+    rows = kernels[:int(os.environ.get("MGAR_BENCH_STDERR_ROWS", "16"))]
+    log("top kernels of the instrumented step (full table: %s)" % path)
+    for r in rows:
+        log("  %-44s %4d x %8.3f ms = %8.2f ms  %s" % (r["kernel"][:44], r["launches_per_step"], r["avg_launch_ms"], r["ms_per_step"],
+                                                       ("%.0f %s = %.2f of peak" % (r["achieved"], r["unit"], r["frac"])) if "frac" in r else ""))
+
+
+def spawn_command(n_gpus, argv, port=None):
+    """`python bench.py --gpus N` outside a launcher: the command that starts the N ranks (one per GPU) as a CHILD process --
+    never an exec, and before torch / the package / anything that touches the GPU is imported in this process."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+class StubStep:
+    """MGAR_BENCH_STUB_STEP=1: protocol rehearsal WITHOUT the model (tests/test_bench_cpu.py, gloo on CPU).  It has the
+    collective behaviour of TrainStep -- one gradient all-reduce per run() / run_eager() -- and counts what it issues; its
+    line is tagged metric "protocol_rehearsal" / data "stub" and is never a measurement."""
+
+    class _M:
+        overlap_branches = False
+
+    def __init__(self, device, ddp):
+        self.module, self.graph, self.ddp = self._M(), None, ddp
+        self.flat = torch.ones(1 << 16, device=device)
+        self.collectives = 0
+
+    def _exchange(self):
+        if self.ddp:
+            import torch.distributed as dist
+            dist.all_reduce(self.flat)
+            self.flat.div_(dist.get_world_size())
+            self.collectives += 1
+
+    def run(self, batch):
+        self._exchange()
+
+    run_eager = run
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the ranks ourselves (child process; its rank 0 prints the line to our stdout)
+        import subprocess
+        cmd = spawn_command(args.gpus, sys.argv[1:])
+        log("starting %d ranks: %s" % (args.gpus, " ".join(cmd)))
+        raise SystemExit(subprocess.call(cmd))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    _import_torch()
+    stub = bool(os.environ.get("MGAR_BENCH_STUB_STEP"))
     # MGAR_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a one-GPU box; RCCL
     # refuses two ranks on one device); the real runs use nccl (= RCCL over xGMI), one rank per GPU.
     backend = os.environ.get("MGAR_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if not torch.cuda.is_available() and not (stub and backend == "gloo"):
+        raise SystemExit("bench.py needs a GPU: the HIP kernels have no CPU fallback")
+    if torch.cuda.is_available():
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     ddp = world > 1
+    dist = None
     if ddp:
         import torch.distributed as dist
         if backend == "nccl":
@@ -284,43 +426,44 @@ def main():
     assert args.clips % world == 0, "global clip batch must divide over the ranks"
     clips_local = args.clips // world
 
-    from multimodal_gar_amd import workload as W
-    torch.backends.cudnn.benchmark = not args.no_miopen_find   # MIOpen find mode for the I3D convolutions
-    log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
-    use_graph = not args.no_graph and not args.ddp_wrapper
-    if use_graph and args.route == "voxel":
-        # the voxeliser in front of the voxel route (torch.unique, data-dependent sizes) synchronises the host and cannot be
-        # captured: this route is timed with host-issued launches on one stream
-        log("route voxel: host-issued launches (the voxeliser's data-dependent sizes cannot be captured into a graph)")
-        use_graph = False
-        args.no_graph = True
-    if args.mode == "train":
-        if args.precision != "fp32":
-            raise SystemExit("bench.py: the backward runs in fp32 only (bf16 is a forward configuration: c2 / c5)")
-        step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp,
-                           manual_allreduce=not args.ddp_wrapper)
-    else:
-        step = W.ForwardStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, precision=args.precision)
-    if args.unfused_voxel_pool:
-        from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack.voxel_pool_modules import NeighborVoxelSAModuleMSG
-        for m in step.module.modules():
-            if isinstance(m, NeighborVoxelSAModuleMSG):
-                m.fused = False
-    # frozen I3D on a side stream (no autograd there: DDP-safe).  Only together with the HIP graph: issued eagerly from
-    # the host the two-stream step measured 362 ms against 269 ms on one stream (and 257 ms as a graph on two).
-    step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
-    step.module.i3d_channels_last = bool(args.i3d_channels_last)
-    batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
-
     def barrier():
         if ddp:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
-    log("model + batch ready; %.1f GB allocated" % (torch.cuda.memory_allocated() / 2 ** 30))
-    if args.phases and rank == 0 and not ddp:
-        phase_timing(step, batch)
-        phase_timing(step, batch)
+    if stub:
+        step, batch, W = StubStep(dev, ddp), None, None
+        use_graph = False
+    else:
+        from multimodal_gar_amd import workload as W
+        torch.backends.cudnn.benchmark = not args.no_miopen_find   # MIOpen find mode for the I3D convolutions
+        log("building model (rank %d/%d, %d clips on this rank)" % (rank, world, clips_local))
+        use_graph = not args.no_graph and not args.ddp_wrapper
+        if use_graph and args.route == "voxel" and not W.voxel_route_capturable():
+            log("route voxel: host-issued launches (the voxeliser's data-dependent sizes cannot be captured into a graph)")
+            use_graph = False
+            args.no_graph = True
+        if args.mode == "train":
+            if args.precision != "fp32":
+                raise SystemExit("bench.py: the backward runs in fp32 only (bf16 is a forward configuration: c2 / c5)")
+            step = W.TrainStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, ddp=ddp,
+                               manual_allreduce=not args.ddp_wrapper)
+        else:
+            step = W.ForwardStep(args.actors, args.points, dev, gat=not args.no_gat, route=args.route, precision=args.precision)
+        if args.unfused_voxel_pool:
+            from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack.voxel_pool_modules import NeighborVoxelSAModuleMSG
+            for m in step.module.modules():
+                if isinstance(m, NeighborVoxelSAModuleMSG):
+                    m.fused = False
+        # frozen I3D on a side stream (no autograd there: DDP-safe).  Only together with the HIP graph: issued eagerly from
+        # the host the two-stream step measured 362 ms against 269 ms on one stream (and 257 ms as a graph on two).
+        step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
+        step.module.i3d_channels_last = bool(args.i3d_channels_last)
+        batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
+        log("model + batch ready; %.1f GB allocated" % (torch.cuda.memory_allocated() / 2 ** 30))
+        if args.phases and rank == 0 and not ddp:
+            phase_timing(step, batch)
+            phase_timing(step, batch)
     if use_graph:
         try:
             step.capture(batch)
@@ -331,7 +474,7 @@ def main():
             raise SystemExit("bench.py: HIP-graph capture failed (%s: %s); rerun with --no-graph"
                              % (type(e).__name__, str(e).splitlines()[0][:200]))
     for i in range(args.warmup):
-        step.run(batch); torch.cuda.synchronize(); log("warmup step %d done" % i)
+        step.run(batch); _sync(); log("warmup step %d done" % i)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -340,7 +483,8 @@ def main():
             log("timed step %d issued" % i)   # host-side only: no sync inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
-    log("timed region: %.1f ms/step, peak mem %.1f GB" % (elapsed / args.steps * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
+    if not stub:
+        log("timed region: %.1f ms/step, peak mem %.1f GB" % (elapsed / args.steps * 1e3, torch.cuda.max_memory_allocated() / 2 ** 30))
     if ddp:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,50 +492,61 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = args.clips * args.steps / elapsed
 
-    roof, kernels, cpu, accounting = None, None, None, None
+    roof, kernels, cpu, accounting, kernels_file = None, None, None, None, None
     if not args.no_kernel_timing:
-        if rank == 0:
-            kernels, accounting = kernel_rooflines(step, batch, clips_local * args.frames, args.points, clips_local, args.precision)
-            # the dominant kernel of the WHOLE step (hand-written or library) that has a roofline; and, beside it, the
-            # dominant hand-written one (the kernels this repo can tune)
-            dom = next(r for r in kernels if "bound" in r and "frac" in r)
-            own = next((r for r in kernels if r.get("class") == "hand_written"), None)
-            keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "class", "launches_per_step",
-                    "ms_per_step", "avg_launch_ms", "algorithmic_bytes_per_launch", "flops_per_launch", "dtype")
-            roof = {k: dom[k] for k in keys if k in dom}
-            roof.setdefault("traffic", None)
-            if own is not None and own is not dom:
-                roof["dominant_hand_written"] = {k: own[k] for k in keys if k in own}
+        # every rank issues the same two extra eager steps (their gradient exchanges are collective); rank 0 instruments its second
+        rec = extra_steps(step, batch, instrument=(rank == 0 and not stub))
+        if rec is not None:
+            kernels, accounting = kernel_rooflines(*rec, clips_local, args.precision)
+            roof = roofline_entry(kernels)
             log("dominant kernel of the step: %s, %.2f ms/step in %d launches, %.0f %s (%.1f %% of peak)"
                 % (roof["kernel"], roof["ms_per_step"], roof["launches_per_step"], roof["achieved"], roof["unit"], 100 * roof["frac"]))
-            log("step accounting (ms): %s" % {k: (round(v, 1) if isinstance(v, float) else v) for k, v in accounting.items() if k != "note"})
-        else:
-            step.run_eager(batch)    # the extra (instrumented on rank 0) step is collective under DDP
+            log("step accounting (ms): %s" % {k: (round(v, 1) if isinstance(v, float) else v) for k, v in accounting.items()})
         barrier()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.mode == "train" and not stub:
         cpu = cpu_baseline(args)
+    if stub:
+        counts = [step.collectives]
+        if ddp:
+            c = torch.tensor([step.collectives], device=dev, dtype=torch.int64)
+            got = [torch.zeros_like(c) for _ in range(world)]
+            dist.all_gather(got, c)
+            counts = [int(g.item()) for g in got]
+        if rank == 0:
+            print(compact_line({"metric": "protocol_rehearsal", "value": value, "unit": "stub steps/sec", "n_gpus": world,
+                                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "data": "stub",
+                                "collectives_per_rank": counts}), flush=True)
+        if ddp:
+            dist.destroy_process_group()
+        return
     if rank == 0:
         what = "fwd+bwd" if args.mode == "train" else "fwd"
+        workload = ("%s: %d clips x %d frames x %d actors x %d pts, %dx%d RGB, %s %s, LiDAR route %s, GAT %s"
+                    % (args.config, args.clips, args.frames, args.actors, args.points, args.height, args.width, args.precision,
+                       "fwd+bwd+Adam" if args.mode == "train" else
+                       "train-mode forward (feature payloads + GEMMs bf16; xyz, distances, indices, BN statistics fp32/int32)"
+                       if args.precision == "bf16" else "train-mode forward", args.route, "off" if args.no_gat else "on"))
         line = {
             "metric": "clips/sec (%s) at %d actors x %dk pts x %d frames" % (what, args.actors, args.points // 1024, args.frames),
             "value": value, "unit": "clips/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
-            "config": {"workload": "%s: %d clips x %d frames x %d actors x %d pts, %dx%d RGB, %s %s, "
-                                   "LiDAR route %s, GAT %s" % (args.config, args.clips, args.frames, args.actors, args.points,
-                                                                args.height, args.width, args.precision,
-                                                                "fwd+bwd+Adam" if args.mode == "train" else
-                                                                "train-mode forward (feature payloads + GEMMs bf16; xyz, distances, "
-                                                                "indices, BN statistics fp32/int32)" if args.precision == "bf16"
-                                                                else "train-mode forward",
-                                                                args.route, "off" if args.no_gat else "on"),
-                       "global_clips": args.clips, "clips_per_gpu": clips_local, "parallelism": "dp%d" % world,
+            "config": {"workload": workload, "global_clips": args.clips, "clips_per_gpu": clips_local, "parallelism": "dp%d" % world,
                        "launch": "hip_graph" if step.graph is not None else "eager",
                        "gradient_exchange": "none" if world == 1 else ("ddp_bucketed" if args.ddp_wrapper else "flat_allreduce"),
                        "trainable_params": W.trainable_parameter_count(step.module)},
-            "roofline": roof, "cpu_baseline": cpu, "step_accounting": accounting, "kernels": kernels,
+            "roofline": roof, "cpu_baseline": cpu, "step_accounting": accounting,
         }
-        print(json.dumps(line), flush=True)
+        if kernels is not None:
+            kernels_file = args.kernels_out or os.path.join(
+                ROOT, "gpurun_out", "bench_kernels_%s_%s_%dgpu_%dclips.json" % (args.config, args.route, world, clips_local))
+            header = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config")}
+            try:
+                write_kernel_table(kernels_file, kernels, accounting, header)
+                line["kernels_file"] = os.path.relpath(kernels_file, ROOT)
+            except OSError as e:   # a read-only tree must not cost the record
+                log("could not write the kernel table (%s)" % e)
+        print(compact_line(line), flush=True)   # the LAST stdout line, < 4 KB
     if ddp:
         dist.destroy_process_group()
 

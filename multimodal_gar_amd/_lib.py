@@ -137,11 +137,18 @@ for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_que
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]
 BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 
+# entry points declared `long long` in include/mgar_ops.h (every other one returns int); listed by name, and
+# tests/test_capi_cpu.py checks the list against the header's declarations
+_LONGLONG_RESULTS = frozenset((
+    "mgar_query_group_stack_inverse_items", "mgar_query_group_stack_inverse_workspace_ints", "mgar_bn_cl_workspace_floats",
+    "mgar_bn_stats_from_partials_workspace_floats", "mgar_voxel_roi_pool_stats_workspace_doubles",
+    "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints"))
+
 _fns = {}
 for _name, _args in _PROTOS.items():
     _fn = getattr(_cdll, _name)  # AttributeError here = the library is stale: rebuild it
     _fn.argtypes = _args
-    _fn.restype = ctypes.c_longlong if _name.endswith(("_workspace_doubles", "bwd_workspace_floats", "_inverse_items", "_workspace_ints", "_partials_workspace_floats", "bn_cl_workspace_floats")) else ctypes.c_int
+    _fn.restype = ctypes.c_longlong if _name in _LONGLONG_RESULTS else ctypes.c_int
     _fns[_name] = _fn
 
 _cdll.mgar_abi_version.restype = ctypes.c_int

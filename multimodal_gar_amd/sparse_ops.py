@@ -221,7 +221,13 @@ def sparse_conv3d(features, indices, spatial_shape, batch_size, weight, kernel, 
     -> (out_features (No, Cout), out_indices (No, 4) int32, out_spatial_shape).  ``cache`` / ``key``: the rulebook of an
     indice_key is built once per sparse tensor lineage and shared (spconv's indice_dict)."""
     rb = cache.get(key) if key is not None else None
-    if rb is None or rb.in_indices.data_ptr() != indices.data_ptr() or rb.in_indices.shape != indices.shape:
+    if rb is not None and rb.in_indices.data_ptr() == indices.data_ptr() and rb.in_indices.shape == indices.shape:
+        # same lineage: the geometry must be the one the table was built for (spconv asserts the same on a shared indice_key)
+        geometry = (_triple(kernel), _triple(stride), _triple(padding), bool(subm), [int(s) for s in spatial_shape])
+        if geometry != (rb.kernel, rb.stride, rb.padding, rb.subm, rb.in_shape):
+            raise ValueError("indice_key %r is shared by convolutions of different geometry: %r vs %r"
+                             % (key, geometry, (rb.kernel, rb.stride, rb.padding, rb.subm, rb.in_shape)))
+    else:
         rb = Rulebook(indices, spatial_shape, batch_size, kernel, stride, padding, subm)
         if key is not None:
             cache[key] = rb

@@ -257,6 +257,13 @@ def voxelize_batch(points, dataset, max_points=5, max_voxels=40000):
     return points_to_voxels_batch(points, dataset.point_cloud_range, dataset.voxel_size, max_points, max_voxels)
 
 
+def voxel_route_capturable():
+    """Whether the voxel route can be recorded into a HIP graph: its voxeliser has data-dependent sizes (torch.unique ->
+    host sync), so not yet."""
+    from .pcdet.datasets.processor import data_processor
+    return bool(getattr(data_processor, "FIXED_CAPACITY", False))
+
+
 def synthetic_loss(outputs):
     """Scalar over all 16 outputs so that every trainable parameter receives a gradient (round-1 placeholder objective;
     kept for tests that need a label-free scalar)."""
@@ -292,11 +299,19 @@ class TrainStep:
         self.model.train()
         self.module = self.model
         self.manual_allreduce = bool(manual_allreduce)
+        # The reference objective is a SUM over the scenes of the batch (what train_func.py:260-269 accumulates over its
+        # micro-steps), so the gradient of the GLOBAL batch is the SUM of the ranks' gradients: all-reduce(SUM), no division --
+        # an N-rank step is then the same update as the one-rank step on the same global batch.  The label-free
+        # synthetic objective is a mean, whose global gradient is the ranks' average.
+        self.grad_average = (loss == "synthetic")
+        self._ddp_wrapped = bool(ddp and not manual_allreduce)
         if ddp and not manual_allreduce:
             from torch.nn.parallel import DistributedDataParallel as DDP
             dev_ids = [device.index] if device.type == "cuda" else None
-            self.model = DDP(self.model, device_ids=dev_ids, find_unused_parameters=False, gradient_as_bucket_view=True,
-                             bucket_cap_mb=64)
+            # the reference objective leaves the cardinality head (and, on the voxel route, conv_out / shared_fc) without a
+            # gradient on every rank: the reducer has to be told, or the buckets holding them are never exchanged
+            self.model = DDP(self.model, device_ids=dev_ids, find_unused_parameters=(loss == "reference"),
+                             gradient_as_bucket_view=True, bucket_cap_mb=64)
         if ddp and manual_allreduce:
             self._sync_from_rank0()
         self.params = [p for p in self.model.parameters() if p.requires_grad]
@@ -311,7 +326,12 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         out = self.model(batch)
         loss = self._loss_of(out, batch)
-        loss.backward()
+        if self._ddp_wrapped and not self.grad_average:
+            # DistributedDataParallel averages the ranks' gradients; a summed objective wants their sum
+            import torch.distributed as dist
+            (loss * dist.get_world_size()).backward()
+        else:
+            loss.backward()
         return loss.detach()
 
     def _loss_of(self, out, batch):
@@ -329,7 +349,8 @@ class TrainStep:
                 dist.broadcast(t, src=0)
 
     def _exchange_gradients(self):
-        """One all-reduce(SUM)/world over all gradients, flattened (~119 MB fp32 per step)."""
+        """One all-reduce(SUM) over all gradients, flattened (~119 MB fp32 per step); divided by the
+        world size only for an averaged objective (see ``grad_average``)."""
         if not self.manual_allreduce:
             return
         import torch.distributed as dist
@@ -345,7 +366,8 @@ class TrainStep:
         grads = [p.grad for p in self.params if p.grad is not None]
         flat = torch._utils._flatten_dense_tensors(grads)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(dist.get_world_size())
+        if self.grad_average:
+            flat.div_(dist.get_world_size())
         for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
             g.copy_(f)
 

@@ -35,6 +35,20 @@ def test_library_exports_every_declared_symbol():
     assert cdll.mgar_abi_version() == _lib.ABI_VERSION
 
 
+def test_binding_return_types_match_the_header():
+    """ctypes' restype per entry point is the header's declared return type (a suffix rule gave
+    mgar_pointwise_dw_bnbwd_workspace_floats -- an `int` -- a 64-bit restype)."""
+    from multimodal_gar_amd import _lib
+    text = open(os.path.join(ROOT, "include", "mgar_ops.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decl = dict((name, ret) for ret, name in re.findall(r"^\s*(long long|int)\s+(mgar_[a-z0-9_]+)\s*\(", text, flags=re.M))
+    assert len(decl) > 100
+    for name, fn in _lib._fns.items():
+        want = ctypes.c_longlong if decl[name] == "long long" else ctypes.c_int
+        assert fn.restype is want, name
+    assert _lib._LONGLONG_RESULTS == {n for n, r in decl.items() if r == "long long" and n in _lib._fns}
+
+
 def test_invalid_arguments_return_codes_not_exit():
     """The reference exit(-1)s on bad input (ball_query.cpp:14-26); the C ABI returns a code.
     Argument checks run before any HIP call, so this is safe without a GPU."""

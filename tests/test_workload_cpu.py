@@ -59,7 +59,7 @@ def _free_port():
     return p
 
 
-def _ddp_worker(rank, world, port, out_path, manual=False):
+def _ddp_worker(rank, world, port, out_path, manual=False, loss="synthetic"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -69,7 +69,7 @@ def _ddp_worker(rank, world, port, out_path, manual=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     with use_cpu_oracle():
-        step = W.TrainStep(3, 256, dev, ddp=True, seed=5, manual_allreduce=manual, loss="synthetic")
+        step = W.TrainStep(3, 256, dev, ddp=True, seed=5, manual_allreduce=manual, loss=loss)
         _no_dropout(step.module)
         full = W.make_batch(11, world, 1, 3, 256, 32, 48, dev)            # the GLOBAL batch: `world` clips
         mine = {k: (v[rank:rank + 1] if torch.is_tensor(v) else v) for k, v in full.items()}
@@ -78,9 +78,7 @@ def _ddp_worker(rank, world, port, out_path, manual=False):
             step._forward_backward(mine)
             step._exchange_gradients()
         else:
-            step.opt.zero_grad(set_to_none=True)
-            loss = W.synthetic_loss(step.model(mine))
-            loss.backward()
+            step._forward_backward(mine)
     if rank == 0:
         g = {n: p.grad.clone() for n, p in step.module.named_parameters() if p.grad is not None}
         torch.save(g, out_path)
@@ -88,15 +86,16 @@ def _ddp_worker(rank, world, port, out_path, manual=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("manual", [False, True])
-def test_ddp_gloo_world2_matches_single_process(tmp_path, manual):
+@pytest.mark.parametrize("manual,loss", [(False, "synthetic"), (True, "synthetic"), (True, "reference"), (False, "reference")])
+def test_ddp_gloo_world2_matches_single_process(tmp_path, manual, loss):
     """DistributedDataParallel (manual=False) and the flattened manual all-reduce of the HIP-graph mode (manual=True)
-    against a single process on the same global batch."""
+    against a single process on the same global batch.  loss="reference": the objective is a SUM over scenes, so two ranks
+    must produce the one-rank gradient of the global batch (sum of the ranks' gradients, not their average: ADVICE r2)."""
     import torch.multiprocessing as mp
     from multimodal_gar_amd import workload as W
     from oracle.cpu_backend import use_cpu_oracle
     out_path = str(tmp_path / "ddp_grads.pt")
-    mp.spawn(_ddp_worker, args=(2, _free_port(), out_path, manual), nprocs=2, join=True)
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out_path, manual, loss), nprocs=2, join=True)
     ddp_grads = torch.load(out_path)
     dev = torch.device("cpu")
     # same thread count as the workers: the tiny I3D feature maps make BatchNorm statistics
@@ -104,7 +103,7 @@ def test_ddp_gloo_world2_matches_single_process(tmp_path, manual):
     threads = torch.get_num_threads()
     torch.set_num_threads(1)
     with use_cpu_oracle():
-        step = W.TrainStep(3, 256, dev, ddp=False, seed=5)
+        step = W.TrainStep(3, 256, dev, ddp=False, seed=5, loss=loss)
         _no_dropout(step.module)
         full = W.make_batch(11, 2, 1, 3, 256, 32, 48, dev)
         # DDP averages the per-rank losses' gradients: reference = mean over the two clips, each run
@@ -113,7 +112,10 @@ def test_ddp_gloo_world2_matches_single_process(tmp_path, manual):
         for r in range(2):
             mine = {k: (v[r:r + 1] if torch.is_tensor(v) else v) for k, v in full.items()}
             mine["n_clips"] = 1
-            (W.synthetic_loss(step.model(mine)) / 2).backward()
+            if loss == "synthetic":
+                (W.synthetic_loss(step.model(mine)) / 2).backward()
+            else:
+                W.reference_loss(step.model(mine), mine).backward()
     torch.set_num_threads(threads)
     checked = 0
     for n, p in step.module.named_parameters():
