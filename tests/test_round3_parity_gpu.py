@@ -1,0 +1,130 @@
+"""Round-3 device parity: rows f3 and a20 on the GPU against reference-generated fixtures.
+
+* train_utils.* ON THE DEVICE vs tests/golden/reference_train_utils.npz (outputs of the reference's own train_utils.py);
+* losses.mgar_losses / mgar_losses_uniform ON THE DEVICE vs the oracle's restatement of train_func.py:133-258
+  (oracle/train_objective.py, CPU), values and gradients;
+* NLBlockND ON THE DEVICE vs tests/golden/reference_torch_blocks.npz (outputs of the reference's own class), eval + train.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from param_fill import fill_deterministic  # noqa: E402
+from train_cases import MAX, make_case  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+GOLD_TU = np.load(os.path.join(HERE, "golden", "reference_train_utils.npz"))
+GOLD_BLOCKS = np.load(os.path.join(HERE, "golden", "reference_torch_blocks.npz"))
+
+
+def _to_dev(c):
+    return {k: v.to(DEV) for k, v in c.items()}
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_train_utils_on_device_match_reference_functions(seed):
+    from multimodal_gar_amd import train_utils as TU
+    c = _to_dev(make_case(seed))
+    tag = "case%d/" % seed
+    pn = TU.get_num_person(c["person_id"])
+    assert pn == GOLD_TU[tag + "person_num"].tolist()
+    assert TU.get_num_social_group(c["social_group_id"]) == GOLD_TU[tag + "social_group_num"].tolist()
+    A_hat = TU.get_adjacency(c["social_group_id"], pn)
+    labels = TU.get_label_from_action(c["action"], pn)
+    for b in range(len(pn)):
+        assert A_hat[b].is_cuda
+        assert np.array_equal(A_hat[b].cpu().numpy(), GOLD_TU[tag + "A_hat%d" % b])
+        assert np.array_equal(TU.get_laplacian(A_hat[b]).cpu().numpy(), GOLD_TU[tag + "lap%d" % b])
+        assert np.array_equal(TU.sid2AdjMat(c["social_group_id"][b]).cpu().numpy(), GOLD_TU[tag + "sid2adj%d" % b])
+        for k in range(7):
+            assert np.array_equal(labels[k][b].cpu().numpy(), GOLD_TU[tag + "label%d_%d" % (k, b)]), (k, b)
+    A_theta = [c["A_theta"][b, :pn[b], :pn[b]] for b in range(len(pn))]
+    got = TU.get_eig_loss2(A_theta, A_hat).detach().cpu().numpy()
+    assert np.allclose(got, GOLD_TU[tag + "eig_loss2"], rtol=1e-9, atol=1e-12), (got, GOLD_TU[tag + "eig_loss2"])
+    A = torch.stack([torch.nn.functional.pad(a, (0, MAX - a.shape[0], 0, MAX - a.shape[0])) for a in A_hat])
+    assert np.array_equal(TU.Adj2Deg(A).cpu().numpy(), GOLD_TU[tag + "adj2deg"])
+    assert np.array_equal(TU.Adj2Lap(A).cpu().numpy(), GOLD_TU[tag + "adj2lap"])
+    # the batched target builders the benchmark's objective uses (uniform actor count): same values as the per-scene ones
+    n = min(pn)
+    A_b = TU.get_adjacency_batched(c["social_group_id"], n)
+    lab_b = TU.get_label_from_action_batched(c["action"], n)
+    for b in range(len(pn)):
+        assert np.array_equal(A_b[b].cpu().numpy(), GOLD_TU[tag + "A_hat%d" % b][:n, :n])
+        for k in range(7):
+            assert np.array_equal(lab_b[k][b].cpu().numpy(), GOLD_TU[tag + "label%d_%d" % (k, b)][:n]), (k, b)
+
+
+def _fake_outputs(seed, batch):
+    g = torch.Generator().manual_seed(seed)
+    sig = lambda *s: torch.rand(*s, generator=g) * 0.98 + 0.01          # noqa: E731  sigmoid-range head outputs
+    return [sig(batch, MAX, MAX)] + [torch.randn(batch, MAX, 4, generator=g) for _ in range(3)] \
+        + [sig(batch, MAX, k) for k in (2, 4, 7, 5)] + [sig(batch, MAX, 4) for _ in range(3)] + [sig(batch, MAX, k) for k in (2, 4, 7, 5)] \
+        + [torch.rand(batch, 1, generator=g) * 4]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_losses_on_device_match_the_oracle_restatement_of_the_reference_loop(seed):
+    from multimodal_gar_amd import losses, train_utils as TU
+    from oracle.train_objective import reference_losses
+    c = make_case(seed)
+    res_cpu = [t.requires_grad_(True) for t in _fake_outputs(seed + 10, 3)]
+    want = reference_losses(res_cpu, c["person_id"], c["social_group_id"], c["action"], c["social_group_activity"], TU)
+    gw = torch.autograd.grad(want["L_total"], res_cpu[:15], allow_unused=True)
+    d = _to_dev(c)
+    res = [t.detach().to(DEV).requires_grad_(True) for t in res_cpu]
+    got = losses.mgar_losses(res, d["person_id"], d["social_group_id"], d["action"], d["social_group_activity"], Loss="L_total")
+    assert got["L_total"].is_cuda
+    for k, v in want.items():
+        assert torch.allclose(torch.as_tensor(got[k]).float().cpu(), torch.as_tensor(v).float(), rtol=1e-5, atol=1e-6), k
+    gg = torch.autograd.grad(got["L_total"], res[:15], allow_unused=True)
+    for a, b in zip(gg, gw):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-7)
+
+
+def test_batched_device_objective_equals_oracle_loop_for_uniform_actor_counts():
+    """losses.mgar_losses_uniform (what workload.reference_loss runs inside the HIP graph, no Python loop over scenes)
+    against the oracle's per-scene loop; reference_semantics=True keeps the assign-instead-of-accumulate terms."""
+    from multimodal_gar_amd import losses, train_utils as TU
+    from oracle.train_objective import reference_losses
+    batch, n = 5, 7
+    rng = np.random.default_rng(4)
+    pid = -np.ones((batch, MAX), np.int64); gid = -np.ones((batch, MAX), np.int64)
+    for b in range(batch):
+        pid[b, :n] = rng.permutation(40)[:n]
+        gid[b, :n] = rng.integers(0, 3, n)
+        gid[b, 0], gid[b, 1], gid[b, 2] = 0, 1, 2
+    action = torch.from_numpy((rng.random((batch, MAX, 27)) < 0.3).astype(np.float32))
+    sga = torch.from_numpy((rng.random((batch, MAX, 27)) < 0.3).astype(np.float32))
+    res_cpu = [t.requires_grad_(True) for t in _fake_outputs(21, batch)]
+    want = reference_losses(res_cpu, torch.from_numpy(pid), torch.from_numpy(gid), action, sga, TU)
+    gw = torch.autograd.grad(want["L_total"], res_cpu[:15], allow_unused=True)
+    res = [t.detach().to(DEV).requires_grad_(True) for t in res_cpu]
+    got = losses.mgar_losses_uniform(res, torch.from_numpy(gid).to(DEV), action.to(DEV), sga.to(DEV), n, Loss="L_total",
+                                     reference_semantics=True)
+    for k in ("L_bce", "L_bce2", "L_pose", "L_interaction", "SG_L_pose", "SG_L_interaction", "L_total"):
+        assert torch.allclose(torch.as_tensor(got[k]).float().cpu(), torch.as_tensor(want[k]).float(), rtol=1e-5, atol=1e-6), k
+    gg = torch.autograd.grad(got["L_total"], res[:15], allow_unused=True)
+    for a, b in zip(gg, gw):
+        assert torch.allclose(a.cpu(), b, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag,cin,cint,dim", [("nl2d", 32, 4, 2), ("nl3d", 24, 3, 3)])
+def test_nlblock_on_device_matches_reference(tag, cin, cint, dim):
+    """Row a20 on the device against the reference class's own outputs (backbone.py:633-687), eval and train mode."""
+    from multimodal_gar_amd.model.backbone import NLBlockND
+    m = fill_deterministic(NLBlockND(cin, cint, mode='dot', dimension=dim), seed=1).to(DEV).eval()
+    x = torch.from_numpy(GOLD_BLOCKS[tag + "_x"]).to(DEV)
+    for mode, key in ((False, "_y"), (True, "_y_train")):
+        m.train(mode)
+        want = GOLD_BLOCKS[tag + key]
+        got = m(x).detach().cpu().numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max(), (tag, mode, np.abs(got - want).max())

@@ -2,9 +2,9 @@
 
 * multimodal_gar_amd/train_utils.py vs the outputs of the REFERENCE's own train_utils.py functions
   (tests/golden/reference_train_utils.npz, made by tests/golden/make_reference_train_utils_golden.py);
-* multimodal_gar_amd/losses.py vs a literal restatement of the loop of train_func.py:133-258 (that file is a script that
-  cannot be imported: it runs at import and opens a network session) written with the reference's own statements order,
-  including its assign-instead-of-accumulate terms; and the batched no-loop version vs the looped one.
+* multimodal_gar_amd/losses.py vs the oracle's restatement of the loss section of train_func.py:133-258
+  (oracle/train_objective.py: that file is a script that cannot be imported -- it runs at import and opens a network
+  session), including its assign-instead-of-accumulate terms; and the batched no-loop version vs the looped one.
 """
 import os
 import sys
@@ -53,55 +53,13 @@ def _fake_outputs(seed, batch, grad=False):
     return [t.requires_grad_(grad) for t in res]
 
 
-def _reference_loop_losses(res, person_id, social_group_id, action, social_group_activity, TU):
-    """train_func.py:133-258, statement by statement (targets from train_utils, which the fixtures pin)."""
-    A_theta, pose_1, pose_2, pose_3, i1, i2, i3, i4, sp1, sp2, sp3, si1, si2, si3, si4, card = res
-    batch_size = A_theta.shape[0]
-    person_num = TU.get_num_person(person_id)
-    cut = lambda t: [t[b, :person_num[b]] for b in range(batch_size)]     # noqa: E731
-    A_theta_list = [A_theta[b, :person_num[b], :person_num[b]] for b in range(batch_size)]
-    pose_l, int_l = [cut(pose_1), cut(pose_2), cut(pose_3)], [cut(i1), cut(i2), cut(i3), cut(i4)]
-    sp_l, si_l = [cut(sp1), cut(sp2), cut(sp3)], [cut(si1), cut(si2), cut(si3), cut(si4)]
-    card_list = [card[b] for b in range(batch_size)]
-    social_group_num = TU.get_num_social_group(social_group_id)
-    A_hat_list = TU.get_adjacency(social_group_id, person_num)
-    label = TU.get_label_from_action(action, person_num)
-    SG_label = TU.get_label_from_action(social_group_activity, person_num)
-    BCELoss, BCE_nr, MSELoss, CELoss = nn.BCELoss(), nn.BCELoss(reduction='none'), nn.MSELoss(reduction='mean'), nn.CrossEntropyLoss()
-    for i in range(batch_size):
-        mask = torch.ones(A_theta_list[i].shape[0], A_theta_list[i].shape[0])
-        mask[torch.eye(A_theta_list[i].shape[0]).bool()] = 0.
-        non_group_mask = A_hat_list[i] == 0
-        Num_group_note = (A_hat_list[i] * mask).sum()
-        Num_total_note = mask.sum()
-        ratio = (Num_total_note - Num_group_note) / (3 * Num_group_note + 1)
-        L_bce2 = ratio * (BCE_nr(A_theta_list[i], A_hat_list[i]) * mask) * A_hat_list[i] + (BCE_nr(A_theta_list[i], A_hat_list[i]) * mask) * non_group_mask
-        L_bce2 = L_bce2.sum() / (mask.sum())
-        L_bce = BCELoss(A_theta_list[i], A_hat_list[i])
-    L_mse = MSELoss(torch.cat(card_list), torch.tensor(social_group_num).float())
-    for i in range(batch_size):
-        L_pose = (CELoss(pose_l[0][i], label[0][i]) + CELoss(pose_l[1][i], label[1][i]) + CELoss(pose_l[2][i], label[2][i]))
-    L_interaction = 0
-    for i in range(batch_size):
-        L_interaction += (BCELoss(int_l[0][i], label[3][i]) + BCELoss(int_l[1][i], label[4][i]) + BCELoss(int_l[2][i], label[5][i])
-                          + BCELoss(int_l[3][i], label[6][i]))
-    for i in range(batch_size):
-        SG_L_pose = (BCELoss(sp_l[0][i], SG_label[0][i]) + BCELoss(sp_l[1][i], SG_label[1][i]) + BCELoss(sp_l[2][i], SG_label[2][i]))
-    SG_L_interaction = 0
-    for i in range(batch_size):
-        SG_L_interaction += (BCELoss(si_l[0][i], SG_label[3][i]) + BCELoss(si_l[1][i], SG_label[4][i]) + BCELoss(si_l[2][i], SG_label[5][i])
-                             + BCELoss(si_l[3][i], SG_label[6][i]))
-    return {"L_bce": L_bce, "L_bce2": L_bce2, "L_mse": L_mse, "L_pose": L_pose, "L_interaction": L_interaction,
-            "SG_L_pose": SG_L_pose, "SG_L_interaction": SG_L_interaction,
-            "L_total": L_bce + (L_pose + L_interaction) + (SG_L_pose + SG_L_interaction)}
-
-
 @pytest.mark.parametrize("seed", [1, 2])
 def test_losses_match_the_reference_loop(seed):
     from multimodal_gar_amd import losses, train_utils as TU
     c = make_case(seed)
     res = _fake_outputs(seed + 10, 3, grad=True)
-    want = _reference_loop_losses(res, c["person_id"], c["social_group_id"], c["action"], c["social_group_activity"], TU)
+    from oracle.train_objective import reference_losses
+    want = reference_losses(res, c["person_id"], c["social_group_id"], c["action"], c["social_group_activity"], TU)
     got = losses.mgar_losses(res, c["person_id"], c["social_group_id"], c["action"], c["social_group_activity"], Loss="L_total")
     for k, v in want.items():
         assert torch.allclose(torch.as_tensor(got[k]).float(), torch.as_tensor(v).float(), rtol=1e-6, atol=1e-7), k
