@@ -49,6 +49,7 @@ int mgar_ktimer_read(int id, double *total_ms, long long *launches, double *tota
 /* adds `flops` to kernel id's total while the timers are on: for stacked-layout launches whose per-sample counts
  * live on the device (the library cannot know sum_i M_i * N_i), the instrumenting caller supplies the work */
 int mgar_ktimer_add_flops(int id, double flops);
+int mgar_ktimer_add_bytes(int id, double bytes);   /* the same for algorithmic bytes (sparse convolutions: pair counts live with the caller) */
 
 /* ======================= pointnet2_batch: (B, N, 3) / (B, C, N) ======================= */
 
@@ -487,16 +488,20 @@ int mgar_dafm_attn_bwd(int S, int total_rows, int D, const int *scene_off, const
  *   out_i  = sum_j alpha_ij * xl_j    (n_nodes, H*C)
  * edge_scale (E,H), may be NULL: multiplies alpha in the aggregation only (PyG applies
  * dropout to alpha in training mode: pass mask/(1-p)); alpha is saved un-scaled.
- * bwd: grad_xl and grad_att are ACCUMULATED into (caller zero-fills them); grad_xr is
- * fully written.
+ * bwd (round 3: no float atomics, every sum in a fixed order -> bit-reproducible gradients): besides the by-target CSR it
+ * takes the same edges indexed BY SOURCE node -- src_rowptr (n_nodes+1), src_edge (E) = edge id (position in col / alpha) of
+ * every outgoing edge of a node, ascending, src_dst (E) = that edge's target node -- and a workspace of
+ * mgar_gatv2_bwd_workspace_floats(n_nodes, H, C, E) floats.  grad_xl, grad_xr, grad_att are fully written.
  */
 /* C must be a multiple of 64 (lanes run along the channel axis). */
 int mgar_gatv2_fwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
                    const float *xr, const float *att, float slope, const float *edge_scale, float *alpha,
                    float *out, void *stream);
-int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const float *xl,
-                   const float *xr, const float *att, float slope, const float *edge_scale, const float *alpha,
-                   const float *grad_out, float *grad_xl, float *grad_xr, float *grad_att, void *stream);
+int mgar_gatv2_bwd(int n_nodes, int H, int C, const int *rowptr, const int *col, const int *src_rowptr, const int *src_edge,
+                   const int *src_dst, const float *xl, const float *xr, const float *att, float slope, const float *edge_scale,
+                   const float *alpha, const float *grad_out, float *workspace, float *grad_xl, float *grad_xr, float *grad_att,
+                   void *stream);
+long long mgar_gatv2_bwd_workspace_floats(int n_nodes, int H, int C, int n_edges);
 
 /* ===================== fused Voxel-RoI pooling ====================
  * One scale of NeighborVoxelSAModuleMSG between mlps_in and mlps_out

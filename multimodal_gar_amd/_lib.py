@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -61,6 +61,7 @@ _PROTOS = {
     "mgar_ktimer_enable": [_I],
     "mgar_ktimer_count": [],
     "mgar_ktimer_add_flops": [_I, ctypes.c_double],
+    "mgar_ktimer_add_bytes": [_I, ctypes.c_double],
     "mgar_ktimer_read": [_I, _P, _P, _P, _P, _I],
     "mgar_rowmajor_dw": [_P, _I, _P, _I, _LL, _I, _I, _P, _P, _P],
     "mgar_bn_workspace_floats": [_I, _I, _I],
@@ -103,7 +104,8 @@ _PROTOS = {
     "mgar_dafm_attn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
     "mgar_dafm_attn_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_gatv2_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P],
-    "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_gatv2_bwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    "mgar_gatv2_bwd_workspace_floats": [_I, _I, _I, _I],
     "mgar_points_in_boxes": [_I, _I, _I, _P, _P, _P, _P],
     "mgar_roipoint_pool3d_fwd": [_I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_image_resample_ksize": [_I, _I],
@@ -142,7 +144,7 @@ BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 _LONGLONG_RESULTS = frozenset((
     "mgar_query_group_stack_inverse_items", "mgar_query_group_stack_inverse_workspace_ints", "mgar_bn_cl_workspace_floats",
     "mgar_bn_stats_from_partials_workspace_floats", "mgar_voxel_roi_pool_stats_workspace_doubles",
-    "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints"))
+    "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints", "mgar_gatv2_bwd_workspace_floats"))
 
 _fns = {}
 for _name, _args in _PROTOS.items():
@@ -245,8 +247,9 @@ _KT_IDS = {}
 _KT_STATE = {"on": False}
 
 
-def note_pair_tests(kernel, pairs):
-    """Instrumented runs only: credit `pairs` (query, point) distance evaluations (8 flop each) to `kernel`."""
+def note_work(kernel, flops=0.0, nbytes=0.0):
+    """Instrumented runs only: credit algorithmic flops / bytes to `kernel` for launches whose work only the caller knows
+    (per-sample counts or pair lists that live on the device)."""
     if not _KT_STATE["on"]:
         return
     if not _KT_IDS:
@@ -254,7 +257,19 @@ def note_pair_tests(kernel, pairs):
         _cdll.mgar_ktimer_name.argtypes = [ctypes.c_int]
         for i in range(raw("mgar_ktimer_count")):
             _KT_IDS[_cdll.mgar_ktimer_name(i).decode()] = i
-    call("mgar_ktimer_add_flops", _KT_IDS[kernel], float(pairs) * 8.0)
+    if flops:
+        call("mgar_ktimer_add_flops", _KT_IDS[kernel], float(flops))
+    if nbytes:
+        call("mgar_ktimer_add_bytes", _KT_IDS[kernel], float(nbytes))
+
+
+def kernel_timing_on():
+    return _KT_STATE["on"]
+
+
+def note_pair_tests(kernel, pairs):
+    """Instrumented runs only: credit `pairs` (query, point) distance evaluations (8 flop each) to `kernel`."""
+    note_work(kernel, flops=float(pairs) * 8.0)
 
 
 def exported_symbols():

@@ -217,6 +217,10 @@ extern "C" __attribute__((visibility("default"))) int mgar_dafm_attn_fwd(int S, 
     MGAR_REQUIRE(sigma != 0.f, "dafm_attn_fwd: sigma == 0");
     if (S == 0 || total_rows == 0) return MGAR_OK;
     MGAR_REQUIRE(scene_off && de_off && q && k && v && de && att && out, "dafm_attn_fwd: null pointer");
+    // attention core only (the projections / FFN are library GEMMs): q, k, v read + out written (4 * rows * D floats), De read and
+    // Att written (rows * n floats each, n = rows / S actors per scene); QK^T and Att V: 4 * rows * n * D flop
+    const double n_avg = (double)total_rows / S;
+    KtScope kt(KT_DAFM_FWD, (hipStream_t)stream, 4.0 * (4.0 * total_rows * D + 2.0 * total_rows * n_avg), 4.0 * total_rows * n_avg * D);
     hipLaunchKernelGGL(dafm_fwd_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, (hipStream_t)stream, S, total_rows, D,
                        scene_off, de_off, q, k, v, de, 1.0f / sigma, scale, att, out);
     return check_launch("dafm_attn_fwd: launch failed");
@@ -233,6 +237,10 @@ extern "C" __attribute__((visibility("default"))) int mgar_dafm_attn_bwd(int S, 
     if (S == 0 || total_rows == 0) return MGAR_OK;
     MGAR_REQUIRE(scene_off && de_off && q && k && v && de && att && grad_out && gmat && grad_q && grad_k && grad_v,
                  "dafm_attn_bwd: null pointer");
+    // q, k, v, grad_out read + 3 gradients written (7 * rows * D), De / Att read + the (rows, n) scratch written and read;
+    // dAtt = gO V^T, dq = dS K, dk = dS^T Q, dv = Att^T gO: 8 * rows * n * D flop
+    const double n_avg = (double)total_rows / S;
+    KtScope kt(KT_DAFM_BWD, (hipStream_t)stream, 4.0 * (7.0 * total_rows * D + 4.0 * total_rows * n_avg), 8.0 * total_rows * n_avg * D);
     hipLaunchKernelGGL(dafm_bwd_rows_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, (hipStream_t)stream, S, total_rows,
                        D, scene_off, de_off, k, v, de, 1.0f / sigma, scale, att, grad_out, gmat, grad_q);
     hipLaunchKernelGGL(dafm_bwd_cols_kernel, dim3(ceil_div(total_rows, 4)), dim3(256), 0, (hipStream_t)stream, S, total_rows,

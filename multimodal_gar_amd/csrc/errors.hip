@@ -25,7 +25,9 @@ const char *const kKtNames[KT_COUNT] = {
     "query_group_bwd", "bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel",
     "bn_bwd_apply_kernel", "bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel",
     "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel", "voxel_roi_pool_fwd", "voxel_roi_pool_bwd", "stem_conv3d_kernel", "query_group_inverse_index",
-    "image_resize_normalize"};
+    "image_resize_normalize",
+    "dafm_attn_fwd", "dafm_attn_bwd", "gatv2_fwd", "gatv2_bwd", "roi_align_fwd", "roi_align_bwd", "voxel_query_kernel", "points_in_boxes_kernel",
+    "roipoint_pool3d_kernel", "spconv_index", "spconv_gemm", "spconv_dw"};
 }  // namespace
 
 void kt_begin(int id, hipStream_t st) {
@@ -51,7 +53,7 @@ void kt_end(int id, hipStream_t st, double bytes, double flops) {
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 10; }
+extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 11; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_last_error(void) { return mgar::g_last_error; }
 
 extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on) {
@@ -69,6 +71,13 @@ extern "C" __attribute__((visibility("default"))) int mgar_ktimer_add_flops(int 
     if (!g_kt_on) return MGAR_OK;
     std::lock_guard<std::mutex> lk(g_kt_mu);
     g_kt[id].flops += flops;
+    return MGAR_OK;
+}
+extern "C" __attribute__((visibility("default"))) int mgar_ktimer_add_bytes(int id, double bytes) {
+    MGAR_REQUIRE(id >= 0 && id < KT_COUNT, "ktimer_add_bytes: bad kernel id");
+    if (!g_kt_on) return MGAR_OK;
+    std::lock_guard<std::mutex> lk(g_kt_mu);
+    g_kt[id].bytes += bytes;
     return MGAR_OK;
 }
 // Waits for the recorded events of kernel `id`, adds their elapsed times, returns the totals since the

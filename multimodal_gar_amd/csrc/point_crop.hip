@@ -130,6 +130,8 @@ PC_API int mgar_points_in_boxes(int batch_size, int boxes_num, int pts_num, cons
     }
     if ((long long)batch_size * pts_num == 0) return MGAR_OK;
     MGAR_REQUIRE(pts && box_idx_of_points && (boxes || boxes_num == 0), "points_in_boxes: null pointer");
+    // points read once, boxes once, one int per point written; batch * pts * boxes box tests
+    KtScope kt(KT_POINTS_IN_BOXES, (hipStream_t)stream, (double)batch_size * (16.0 * pts_num + 28.0 * boxes_num));
     hipLaunchKernelGGL(points_in_boxes_kernel, dim3(ceil_div(pts_num, PC_THREADS), batch_size), dim3(PC_THREADS), 0, (hipStream_t)stream,
                        boxes_num, pts_num, boxes, pts, box_idx_of_points);
     return check_launch("points_in_boxes: launch failed");
@@ -153,6 +155,10 @@ PC_API int mgar_roipoint_pool3d_fwd(int batch_size, int pts_num, int boxes_num, 
         (void)hipFuncSetAttribute((const void *)roipoint_pool3d_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
+    // every (box, sample) workgroup scans its cloud (12 B per point, cache-resident across the boxes of a sample: counted once per
+    // sample) and writes its crop
+    KtScope kt(KT_ROIPOINT_POOL, (hipStream_t)stream, (double)batch_size * (12.0 * pts_num + 28.0 * boxes_num +
+                                                          (double)boxes_num * sampled_pts_num * 4.0 * (3 + feature_in_len) * 2.0));
     hipLaunchKernelGGL(roipoint_pool3d_kernel, dim3(boxes_num, batch_size), dim3(PC_THREADS), lds, (hipStream_t)stream, pts_num, boxes_num,
                        feature_in_len, sampled_pts_num, xyz, boxes3d, pts_feature, pooled_features, pooled_empty_flag);
     return check_launch("roipoint_pool3d_fwd: launch failed");

@@ -131,6 +131,8 @@ static int roi_align_fwd_impl(const T *input, int N, int C, int H, int W, const 
     if (total == 0) return MGAR_OK;
     MGAR_REQUIRE(input && rois && out, "roi_align_fwd: null pointer");
     const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    // the feature map read once + the RoIs + the crops written
+    KtScope kt(KT_ROI_ALIGN_FWD, (hipStream_t)stream, sizeof(T) * ((double)N * C * H * W + (double)total) + 20.0 * K);
     hipLaunchKernelGGL(roi_align_fwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, input, C, H, W, rois,
                        pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, out);
     return check_launch("roi_align_fwd: launch failed");
@@ -162,6 +164,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_roi_align_bwd(const f
     if (total == 0) return MGAR_OK;
     MGAR_REQUIRE(grad_out && rois && grad_input, "roi_align_bwd: null pointer");
     const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    KtScope kt(KT_ROI_ALIGN_BWD, (hipStream_t)stream, 4.0 * ((double)total + 4.0 * (double)total) + 20.0 * K);   // crops' gradient read + <= 4 taps per sample written
     hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, total, grad_out, C, H, W,
                        rois, pooled_h, pooled_w, spatial_scale, sampling_ratio, aligned, grad_input);
     return check_launch("roi_align_bwd: launch failed");

@@ -515,6 +515,7 @@ SP_API int mgar_voxel_hash_build(int N, const int *coords, int Z, int Y, int X, 
                  "voxel_hash_build: capacity must be a power of two >= 2 N");
     if (N == 0) return MGAR_OK;
     MGAR_REQUIRE(coords && table_keys && table_vals, "voxel_hash_build: null pointer");
+    KtScope kt(KT_SPCONV_INDEX, (hipStream_t)stream, 16.0 * N + 12.0 * N);   // coords read, one (key, value) slot written per site
     hipLaunchKernelGGL(sph_build_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, (hipStream_t)stream, N, coords, Z, Y, X, table_keys,
                        table_vals, capacity - 1);
     return check_launch("voxel_hash_build: launch failed");
@@ -527,6 +528,7 @@ SP_API int mgar_voxel_hash_lookup(int M, const int *coords, int Z, int Y, int X,
     MGAR_REQUIRE(M >= 0 && Z > 0 && Y > 0 && X > 0 && capacity > 0 && (capacity & (capacity - 1)) == 0, "voxel_hash_lookup: bad sizes");
     if (M == 0) return MGAR_OK;
     MGAR_REQUIRE(coords && table_keys && table_vals && rows, "voxel_hash_lookup: null pointer");
+    KtScope kt(KT_SPCONV_INDEX, (hipStream_t)stream, 16.0 * M + 12.0 * M + 4.0 * M);   // coords, one probed slot, one row id
     hipLaunchKernelGGL(sph_lookup_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, (hipStream_t)stream, M, coords, Z, Y, X, table_keys,
                        table_vals, capacity - 1, rows);
     return check_launch("voxel_hash_lookup: launch failed");
@@ -546,6 +548,7 @@ SP_API int mgar_spconv_rulebook(int n_sites, const int *site_coords, const int *
     const int K = g.kz * g.ky * g.kx;
     const long long total = (long long)n_sites * K;
     MGAR_REQUIRE(total / 256 < 2147483647LL, "spconv_rulebook: too many (site, offset) pairs");
+    KtScope kt(KT_SPCONV_INDEX, (hipStream_t)stream, 16.0 * n_sites + (double)total * (12.0 + 4.0));   // one probe + one table entry per (site, offset)
     if (inverse)
         hipLaunchKernelGGL(sp_neighbors_inverse_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, K, site_coords,
                            g, table_keys, table_vals, capacity - 1, nbr);
@@ -565,6 +568,7 @@ SP_API int mgar_spconv_output_keys(int n_in, const int *in_coords, const int *ge
     const int K = g.kz * g.ky * g.kx;
     const long long total = (long long)n_in * K;
     MGAR_REQUIRE(total / 256 < 2147483647LL, "spconv_output_keys: too many (site, offset) pairs");
+    KtScope kt(KT_SPCONV_INDEX, (hipStream_t)stream, 16.0 * n_in + 8.0 * (double)total);
     hipLaunchKernelGGL(sp_output_keys_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, total, K, in_coords, g, keys);
     return check_launch("spconv_output_keys: launch failed");
 }
@@ -589,6 +593,9 @@ SP_API int mgar_spconv_gather_gemm(int No, int K, int Cin, int Cout, const float
         (void)hipFuncSetAttribute((const void *)spconv_gather_gemm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
+    // table (No, K) read, out written; the gathered input rows and the flops depend on the number of pairs, which the caller
+    // credits (mgar_ktimer_add_bytes / _flops)
+    KtScope kt(KT_SPCONV_GEMM, (hipStream_t)stream, 4.0 * No * ((double)K + Cout) + 4.0 * (double)K * Cin * Cout);
     hipLaunchKernelGGL(spconv_gather_gemm_kernel, dim3(ceil_div(No, SC_ROWS)), dim3(256), lds, (hipStream_t)stream, No, K, Cin, Cout, in, nbr,
                        w, flip_k, out);
     return check_launch("spconv_gather_gemm: launch failed");
@@ -612,6 +619,7 @@ SP_API int mgar_spconv_dw(int No, int K, int Cin, int Cout, const float *in, con
         (void)hipFuncSetAttribute((const void *)spconv_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds = lds;
     }
+    KtScope kt(KT_SPCONV_DW, (hipStream_t)stream, 4.0 * No * ((double)K + Cout) + 4.0 * (double)K * Cin * Cout);
     hipLaunchKernelGGL(spconv_dw_kernel, dim3(K, (No + SC_DW_CHUNK - 1) / SC_DW_CHUNK), dim3(256), lds, (hipStream_t)stream, No, K, Cin,
                        Cout, in, nbr, dout, partial);
     return check_launch("spconv_dw: launch failed");
@@ -632,6 +640,7 @@ SP_API int mgar_spconv_pairs_dw(int n_items, int K, int Cin, int Cout, const flo
     }
     MGAR_REQUIRE(item_start && dw && (n_items == 0 || (in && dout && pair_i && pair_o && items && partial)), "spconv_pairs_dw: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    KtScope kt(KT_SPCONV_DW, st, 4.0 * (double)K * Cin * Cout);   // + 8 B of indices and both rows per pair: credited by the caller
     if (n_items > 0) {
         const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 31) & ~31;
         const size_t lds = (size_t)SC_ROWS * (CinP + 1 + CoutP + 1) * sizeof(float);
@@ -679,6 +688,7 @@ SP_API int mgar_spconv_pairs_gemm(int K, int Cs, int Cd, const float *src, const
         (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_lds[variant] = lds;
     }
+    KtScope kt(KT_SPCONV_GEMM, st, 4.0 * (double)K * Cs * Cd);   // all offsets of the layer = one row of the table; pairs credited by the caller
     for (int k = 0; k < K; ++k) {
         const int n = item_start_host[k + 1] - item_start_host[k];
         if (n <= 0) continue;

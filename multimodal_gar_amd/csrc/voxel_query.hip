@@ -124,6 +124,9 @@ static int voxel_query_launch(bool hash, int M, int R1, int R2, int R3, int nsam
         (void)hipFuncSetAttribute((const void *)voxel_query_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         attr_set = true;
     }
+    const double cells = (2.0 * z_range + 1) * (2.0 * y_range + 1) * (2.0 * x_range + 1);
+    // 12 M + 16 M + 4 M nsample + 4 K per query of table lookups (hit xyz gathers are data dependent: not counted)
+    KtScope kt(KT_VOXEL_QUERY, (hipStream_t)stream, (double)M * (28.0 + 4.0 * nsample + 4.0 * cells));
     if (hash)
         hipLaunchKernelGGL(voxel_query_kernel<true>, dim3(ceil_div(M, VQ_THREADS)), dim3(VQ_THREADS), lds, (hipStream_t)stream, M, R1, R2,
                            R3, nsample, radius * radius, z_range, y_range, x_range, new_xyz, xyz, new_coords, (const int *)nullptr,

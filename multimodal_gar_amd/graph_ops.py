@@ -25,7 +25,7 @@ def glorot_(t: torch.Tensor):
 
 class _GatAggregate(Function):
     @staticmethod
-    def forward(ctx, xl, xr, att, rowptr, col, edge_scale, heads, slope):
+    def forward(ctx, xl, xr, att, rowptr, col, edge_scale, heads, slope, by_source=None):
         xl, xr, att = xl.contiguous(), xr.contiguous(), att.contiguous()
         n = xl.shape[0]
         c = xl.shape[1] // heads
@@ -34,25 +34,40 @@ class _GatAggregate(Function):
         L.call("mgar_gatv2_fwd", n, heads, c, L.iptr(rowptr), L.iptr(col), L.fptr(xl), L.fptr(xr), L.fptr(att),
                float(slope), L.fptr(edge_scale) if edge_scale is not None else None, L.fptr(alpha), L.fptr(out),
                L.stream_of(xl))
-        ctx.save_for_backward(xl, xr, att, rowptr, col, alpha, edge_scale if edge_scale is not None else torch.empty(0))
+        if by_source is None:
+            by_source = csr_by_source(rowptr, col)
+        ctx.save_for_backward(xl, xr, att, rowptr, col, alpha, edge_scale if edge_scale is not None else torch.empty(0), *by_source)
         ctx.cfg = (heads, float(slope), edge_scale is not None)
         return out, alpha
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out, grad_alpha_unused):
-        xl, xr, att, rowptr, col, alpha, edge_scale = ctx.saved_tensors
+        xl, xr, att, rowptr, col, alpha, edge_scale, src_rowptr, src_edge, src_dst = ctx.saved_tensors
         heads, slope, has_scale = ctx.cfg
         n = xl.shape[0]
         c = xl.shape[1] // heads
-        gxl = torch.zeros_like(xl)
-        gxr = torch.empty_like(xr)
-        gatt = torch.zeros_like(att)
+        gxl, gxr, gatt = torch.empty_like(xl), torch.empty_like(xr), torch.empty_like(att)
         grad_out = grad_out.contiguous()
-        L.call("mgar_gatv2_bwd", n, heads, c, L.iptr(rowptr), L.iptr(col), L.fptr(xl), L.fptr(xr), L.fptr(att), slope,
-               L.fptr(edge_scale) if has_scale else None, L.fptr(alpha), L.fptr(grad_out), L.fptr(gxl),
-               L.fptr(gxr), L.fptr(gatt), L.stream_of(xl))
-        return gxl, gxr, gatt, None, None, None, None, None
+        ws = torch.empty((L.raw("mgar_gatv2_bwd_workspace_floats", n, heads, c, col.numel()),), dtype=torch.float32, device=xl.device)
+        L.call("mgar_gatv2_bwd", n, heads, c, L.iptr(rowptr), L.iptr(col), L.iptr(src_rowptr), L.iptr(src_edge), L.iptr(src_dst),
+               L.fptr(xl), L.fptr(xr), L.fptr(att), slope, L.fptr(edge_scale) if has_scale else None, L.fptr(alpha),
+               L.fptr(grad_out), L.fptr(ws), L.fptr(gxl), L.fptr(gxr), L.fptr(gatt), L.stream_of(xl))
+        return gxl, gxr, gatt, None, None, None, None, None, None
+
+
+def csr_by_source(rowptr, col):
+    """The by-target CSR (rowptr, col) re-indexed BY SOURCE node for the atomics-free backward (include/mgar_ops.h,
+    mgar_gatv2_bwd): (src_rowptr (n+1), src_edge (E) edge ids of every node's outgoing edges, ascending, src_dst (E) their
+    targets), all int32.  No host sync (graph-capturable)."""
+    n = rowptr.numel() - 1
+    e = col.numel()
+    dst = torch.repeat_interleave(torch.arange(n, device=col.device, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]).long(),
+                                  output_size=e)
+    order = torch.argsort(col.long(), stable=True)
+    src_rowptr = torch.zeros(n + 1, dtype=torch.int32, device=col.device)
+    src_rowptr[1:] = torch.cumsum(torch.bincount(col.long(), minlength=n)[:n], 0).int()
+    return src_rowptr, order.int().contiguous(), dst[order].contiguous()
 
 
 def edges_to_csr(edge_index: torch.Tensor, num_nodes: int, add_self_loops: bool = True):
@@ -107,11 +122,12 @@ class GATv2Conv(nn.Module):
         # scenes are cached by the caller), which also keeps the boolean-mask / bincount host syncs out of the step
         cached = getattr(edge_index, "_mgar_csr", None)
         if cached is not None and cached[0] == (n, self.add_self_loops, edge_index._version):
-            rowptr, col = cached[1]
+            rowptr, col, by_source = cached[1]
         else:
             rowptr, col = edges_to_csr(edge_index, n, self.add_self_loops)
+            by_source = csr_by_source(rowptr, col) if x.is_cuda else None
             try:
-                edge_index._mgar_csr = ((n, self.add_self_loops, edge_index._version), (rowptr, col))
+                edge_index._mgar_csr = ((n, self.add_self_loops, edge_index._version), (rowptr, col, by_source))
             except (AttributeError, RuntimeError):
                 pass
         edge_scale = None
@@ -121,7 +137,7 @@ class GATv2Conv(nn.Module):
         # node features of one actor graph are A x 4096 floats: the edge-softmax / aggregate kernel stays fp32 on every
         # configuration (bf16 configurations: lin_l / lin_r run as bf16 GEMMs under autocast and are widened here)
         out, alpha = _GatAggregate.apply(xl.float(), xr.float(), self.att.view(self.heads, self.out_channels).float(), rowptr, col,
-                                         edge_scale, self.heads, self.negative_slope)
+                                         edge_scale, self.heads, self.negative_slope, by_source)
         out = out if self.concat else out.view(n, self.heads, self.out_channels).mean(dim=1)
         if self.bias is not None:
             out = out + self.bias

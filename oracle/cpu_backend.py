@@ -183,7 +183,7 @@ def dafm_attention_cpu(q, k, v, de_flat, scene_off, de_off, sigma, scale):
 
 class _GatAggregateCpu:
     @staticmethod
-    def apply(xl, xr, att, rowptr, col, edge_scale, heads, slope):
+    def apply(xl, xr, att, rowptr, col, edge_scale, heads, slope, by_source=None):
         n = xl.shape[0]
         c = xl.shape[1] // heads
         xl3, xr3 = xl.view(n, heads, c), xr.view(n, heads, c)
