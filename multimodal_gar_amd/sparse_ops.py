@@ -80,6 +80,12 @@ class Rulebook:
         self._geom = geom
         self.inv = None             # built on demand (inverse_table): only the table-driven data gradient of a strided conv reads it
 
+    def pair_count(self):
+        """Number of (output site, offset) pairs with a neighbour (host int; one sync, cached: instrumentation only)."""
+        if getattr(self, "_pair_count", None) is None:
+            self._pair_count = int((self.nbr >= 0).sum().item())
+        return self._pair_count
+
     def inverse_table(self):
         """(N_in, K) int32: the output row input i reaches through offset k, or -1 (strided convolutions; a submanifold one uses
         its forward table with mirrored offsets)."""
@@ -146,6 +152,17 @@ def _pow2(v):
     return v >= 1 and (v & (v - 1)) == 0
 
 
+def _note(kernel, rb, c_src, c_dst, n_src, n_dst, rmw):
+    """Instrumented runs (bench.py): credit a sparse product's algorithmic work -- 2 P C_src C_dst flop over the P (site,
+    offset) pairs of the rulebook; bytes = source rows once + destination rows once (twice for the read-modify-write pair
+    kernels) + 8 B of pair indices each."""
+    if not L.kernel_timing_on():
+        return
+    p = rb.pair_count()
+    L.note_work(kernel, flops=2.0 * p * c_src * c_dst,
+                nbytes=4.0 * (n_src * c_src + (2 if rmw else 1) * n_dst * c_dst) + 8.0 * p)
+
+
 def _gather_gemm(n_out, k, cin, cout, feats, nbr, w, flip):
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
     L.call("mgar_spconv_gather_gemm", n_out, k, cin, cout, L.fptr(feats), L.iptr(nbr), L.fptr(w), int(flip), L.fptr(out),
@@ -180,8 +197,10 @@ class _SparseConv(Function):
         k, cin, cout = w.shape
         if PAIRS_FORWARD and _pow2(cin) and max(cin, cout) <= 128:
             out = _pairs_gemm(rb, rb.nbr.shape[0], feats, w, False)
+            _note("spconv_gemm", rb, cin, cout, feats.shape[0], out.shape[0], True)
         else:
             out = _gather_gemm(rb.nbr.shape[0], k, cin, cout, feats, rb.nbr, w, 0)
+            _note("spconv_gemm", rb, cin, cout, feats.shape[0], 0, False)       # the output write is in the launcher's figure
         ctx.save_for_backward(feats, w)
         ctx.rb = rb
         return out
@@ -198,6 +217,7 @@ class _SparseConv(Function):
             wt = w.transpose(1, 2).contiguous()                                   # (K, Cout, Cin)
             if PAIRS_DGRAD and _pow2(cout) and max(cin, cout) <= 128:
                 dfeats = _pairs_gemm(rb, feats.shape[0], dout, wt, True)
+                _note("spconv_gemm", rb, cout, cin, dout.shape[0], feats.shape[0], True)
             else:
                 dfeats = _gather_gemm(feats.shape[0], k, cout, cin, dout, rb.nbr if rb.subm else rb.inverse_table(), wt, 1 if rb.subm else 0)
         if ctx.needs_input_grad[1] and _pow2(cin) and _pow2(cout) and max(cin, cout) <= 128:
@@ -207,6 +227,7 @@ class _SparseConv(Function):
             dw = torch.empty((k, cin, cout), dtype=torch.float32, device=feats.device)
             L.call("mgar_spconv_pairs_dw", n_items, k, cin, cout, L.fptr(feats), L.fptr(dout), L.iptr(pair_i), L.iptr(pair_o), L.iptr(items),
                    L.iptr(item_start), L.fptr(part), L.fptr(dw), L.stream_of(feats))
+            _note("spconv_dw", rb, cin, cout, feats.shape[0], dout.shape[0], False)
         elif ctx.needs_input_grad[1]:
             n_out = rb.nbr.shape[0]
             nchunk = L.raw("mgar_spconv_dw_chunks", n_out)

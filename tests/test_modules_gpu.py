@@ -22,6 +22,8 @@ def close(a, b, rtol=1e-4, atol=1e-5):
     assert a.shape == b.shape
     scale = b.abs().max().item() + 1e-12
     err = (a - b).abs().max().item()
+    from conftest import record_error
+    record_error("", err, scale, rtol)
     assert err <= atol + rtol * scale, "max err %g vs scale %g" % (err, scale)
 
 

@@ -35,6 +35,8 @@ def _close(name, got, want, rtol, atol=1e-6):
     assert got.shape == want.shape, (name, got.shape, want.shape)
     scale = np.abs(want).max() + 1e-12
     err = np.abs(got - want).max()
+    from conftest import record_error
+    record_error(name, err, scale, rtol)
     assert err <= atol + rtol * scale, "%s: max err %g vs scale %g" % (name, err, scale)
 
 

@@ -24,6 +24,8 @@ def close(a, b, rtol=1e-4, atol=1e-5, what=""):
     assert a.shape == b.shape, (what, a.shape, b.shape)
     scale = b.abs().max().item() + 1e-12
     err = (a - b).abs().max().item()
+    from conftest import record_error
+    record_error(what, err, scale, rtol)
     assert err <= atol + rtol * scale, "%s: max err %g vs scale %g" % (what, err, scale)
 
 
