@@ -104,6 +104,13 @@ int mgar_fps_batch(int b, int n, int m, const float *points, float *temp, int *i
 int mgar_morton_codes(int b, int n, const float *points, int *codes, void *stream);
 int mgar_fps_batch_perm(int b, int n, int m, const float *points, float *temp, const int *perm, int *idx,
                         void *stream);
+/* The same for clouds of 16 385 .. 65 536 points (BASELINE config c5), which do not fit the register file: pruning at the
+ * granularity of 256-point units; the running minima stay in registers, the coordinates are re-ordered once into `workspace`
+ * (mgar_fps_batch_buckets_workspace_floats(b, n) floats, 16-byte aligned) and only the units a new sample can still lower are
+ * re-read.  Same indices and final temp as mgar_fps_batch, bit for bit, for any permutation. */
+long long mgar_fps_batch_buckets_workspace_floats(int b, int n);
+int mgar_fps_batch_buckets(int b, int n, int m, const float *points, float *temp, const int *perm, float *workspace, int *idx,
+                           void *stream);
 
 /* three_nn_wrapper   pointnet2_api.cpp:21;  kernel interpolate_gpu.cu:16-59
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3). */

@@ -33,6 +33,8 @@ _PROTOS = {
     "mgar_fps_batch": [_I, _I, _I, _P, _P, _P, _P],
     "mgar_morton_codes": [_I, _I, _P, _P, _P],
     "mgar_fps_batch_perm": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_fps_batch_buckets": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "mgar_fps_batch_buckets_workspace_floats": [_I, _I],
     "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
@@ -144,7 +146,8 @@ BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 _LONGLONG_RESULTS = frozenset((
     "mgar_query_group_stack_inverse_items", "mgar_query_group_stack_inverse_workspace_ints", "mgar_bn_cl_workspace_floats",
     "mgar_bn_stats_from_partials_workspace_floats", "mgar_voxel_roi_pool_stats_workspace_doubles",
-    "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints", "mgar_gatv2_bwd_workspace_floats"))
+    "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints", "mgar_gatv2_bwd_workspace_floats",
+    "mgar_fps_batch_buckets_workspace_floats"))
 
 _fns = {}
 for _name, _args in _PROTOS.items():

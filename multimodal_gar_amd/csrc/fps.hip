@@ -584,6 +584,203 @@ __global__ __launch_bounds__(1024) void fps_stream_reg_kernel(FpsArgs A) {
     }
 }
 
+// ---- clouds of 16 385 .. 65 536 points with bucketed pruning (round 3; BASELINE config c5) ------------------------------
+// fps_stream_reg_kernel re-reads the whole cloud for every sample (254 of 473 ms of the c5 step).  Here the pruning of
+// fps_pruned_kernel is applied at the granularity of UNITS of 256 points (Morton order: a unit is a compact cluster):
+//   * the running minimum distances of all points stay in registers (4 * NU per lane, NU units per wave, 16 waves);
+//   * coordinates do NOT fit on chip: they live in a workspace as float4 {x, y, z, p} in sorted order (p = the point's
+//     tie-break priority, from which k is recovered) -- a unit is 4 KB contiguous, a lane's 4 points one 64-byte run;
+//   * every unit keeps its bounding box and its current maximum distance in the registers of lane u of its wave, and its
+//     candidate record {key, x, y, z, k} in LDS.  Per sample a wave tests its NU boxes in one vector step (lane u <-> unit u);
+//     only units the new sample can still lower are loaded (4 float4 per lane), updated and re-reduced; a wave with no such
+//     unit re-publishes its cached candidate without touching anything.
+// After the first few hundred samples 1-3 of the 256 units of a cloud are live per sample, so a sample costs the latency of one
+// 4 KB read from L2 / MALL + one unit update + the two reductions instead of a pass over 768 KB.
+// Exactness: same distance expression, running minimum and (value, ~p) keys as the other kernels; inside a lane the 4 points of
+// a unit are ordered by ascending p (prep kernel), so the strict '>' scan keeps the reference's survivor; the pruning test is
+// conservative by the same 1e-5 margin.  Any permutation gives the exact result (tests: Morton, random).
+constexpr int FB_UNIT = 256;            // points per unit = 64 lanes x 4
+constexpr int FB_NOPT = 0x7FFFFFFF;     // priority of a padding slot
+
+struct alignas(32) FbCand {
+    unsigned key_lo, key_hi;
+    float x, y, z;
+    int k;
+    float best;
+    int pad;
+};
+
+// perm (b, n) -> sorted (b, cap) float4 {x, y, z, p}, groups of 4 consecutive positions ordered by ascending p; padding p = NOPT
+__global__ __launch_bounds__(256) void fps_bucket_prep_kernel(const float *__restrict__ points, const int *__restrict__ perm, int n,
+                                                              int cap, float4 *__restrict__ sorted) {
+    const int cloud = blockIdx.y;
+    const int g = blockIdx.x * 256 + threadIdx.x;   // group of 4 positions
+    if (g * 4 >= cap) return;
+    const int L = (n + 1023) >> 10;
+    const float *P = points + (size_t)cloud * n * 3;
+    const int *pm = perm + (size_t)cloud * n;
+    float4 v[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int q = g * 4 + s;
+        if (q < n) {
+            const int k = pm[q];
+            const int pr = (int)(__brev((unsigned)(k & 1023)) >> 22) * L + (k >> 10);
+            v[s] = make_float4(P[k * 3 + 0], P[k * 3 + 1], P[k * 3 + 2], __int_as_float(pr));
+        } else {
+            v[s] = make_float4(0.f, 0.f, 0.f, __int_as_float(FB_NOPT));
+        }
+    }
+    // 4-element sorting network on p (ascending)
+    auto cswap = [&](int i, int j) {
+        if (__float_as_int(v[i].w) > __float_as_int(v[j].w)) { const float4 t = v[i]; v[i] = v[j]; v[j] = t; }
+    };
+    cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+    float4 *out = sorted + (size_t)cloud * cap + (size_t)g * 4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) out[s] = v[s];
+}
+
+template <int NU>
+__global__ __launch_bounds__(1024) void fps_bucket_kernel(FpsArgs A, const float4 *__restrict__ sorted, int cap) {
+    constexpr int NW = 16;
+    __shared__ FpsSlot slots[2][16];
+    __shared__ FpsSlot cached[16];
+    __shared__ FbCand cand[NW][NU];
+    const int cloud = blockIdx.x;
+    const int n = A.n_batch, m = A.m_batch;
+    if (m <= 0 || n <= 0) return;
+    const int L = (n + 1023) >> 10;
+    const float *__restrict__ P = A.points + (size_t)cloud * n * 3;
+    float *__restrict__ temp = A.temp + (size_t)cloud * n;
+    int *__restrict__ out = A.idx + (size_t)cloud * m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // this wave's units (a wave-uniform base: scalar registers) and this lane's 4 points inside a unit (a 32-bit lane offset)
+    const float4 *__restrict__ wbase = sorted + (size_t)cloud * cap + (size_t)wave * NU * FB_UNIT;
+    const float4 *__restrict__ mine = wbase + lane * 4;
+    auto k_of = [&](int pr) { const int hi = pr / L; return (int)(__brev((unsigned)hi) >> 22) + (pr - hi * L) * 1024; };
+
+    float D[NU * 4];
+    const float inf = __builtin_inff();
+    // per-unit data in lane u: bounding box + cached maximum
+    float bx0 = inf, by0 = inf, bz0 = inf, bx1 = -inf, by1 = -inf, bz1 = -inf, cmax = inf;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        float lx0 = inf, ly0 = inf, lz0 = inf, lx1 = -inf, ly1 = -inf, lz1 = -inf;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float4 v = mine[u * FB_UNIT + s];
+            const int pr = __float_as_int(v.w);
+            const bool ok = pr != FB_NOPT;
+            D[u * 4 + s] = ok ? temp[k_of(pr)] : -1.f;
+            if (ok) {
+                lx0 = fminf(lx0, v.x); lx1 = fmaxf(lx1, v.x);
+                ly0 = fminf(ly0, v.y); ly1 = fmaxf(ly1, v.y);
+                lz0 = fminf(lz0, v.z); lz1 = fmaxf(lz1, v.z);
+            }
+        }
+        const float ux0 = -wave_max(-lx0), uy0 = -wave_max(-ly0), uz0 = -wave_max(-lz0);
+        const float ux1 = wave_max(lx1), uy1 = wave_max(ly1), uz1 = wave_max(lz1);
+        if (lane == u) { bx0 = ux0; by0 = uy0; bz0 = uz0; bx1 = ux1; by1 = uy1; bz1 = uz1; }
+    }
+
+    float x1 = P[0], y1 = P[1], z1 = P[2];
+    if (tid == 0) out[0] = 0;
+    bool other_stale = false;
+
+    for (int j = 1; j < m; ++j) {
+        FpsSlot *buf = slots[j & 1];
+        // lane u tests unit u's box (lanes >= NU never vote)
+        const float ex = fmaxf(fmaxf(bx0 - x1, x1 - bx1), 0.f), ey = fmaxf(fmaxf(by0 - y1, y1 - by1), 0.f);
+        const float ez = fmaxf(fmaxf(bz0 - z1, z1 - bz1), 0.f);
+        const float dmin2 = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+        const bool live = lane < NU && (j == 1 || dmin2 < cmax);
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(live);
+        if (mask != 0ull) {  // wave-uniform
+            unsigned lo = (unsigned)lane * 4u;
+            asm volatile("" : "+v"(lo));   // re-materialised per sample: otherwise 2 * NU 64-bit addresses are hoisted out of the loop and spill
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                if ((mask >> u) & 1ull) {  // wave-uniform
+                    float4 v[4];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) v[s] = wbase[u * FB_UNIT + lo + s];
+                    float best = -1.f, wx = 0.f, wy = 0.f, wz = 0.f;
+                    int wp = FB_NOPT;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float d = d2_of(v[s].x - x1, v[s].y - y1, v[s].z - z1);
+                        // a padding slot holds -1 and zero coordinates: min(d, -1) = -1 keeps it out for ever
+                        const float d2 = vmin(d, D[u * 4 + s]);
+                        D[u * 4 + s] = d2;
+                        const bool gt = d2 > best;
+                        wx = gt ? v[s].x : wx; wy = gt ? v[s].y : wy; wz = gt ? v[s].z : wz;
+                        wp = gt ? __float_as_int(v[s].w) : wp;
+                        best = vmax(best, d2);
+                    }
+                    const unsigned long long mykey = ((unsigned long long)ordered_bits(best) << 32) |
+                                                     (unsigned long long)(0xFFFFFFFFu - (unsigned)wp);
+                    const unsigned long long wkey = wave_umax64(mykey);
+                    const unsigned ob = (unsigned)(wkey >> 32);
+                    const float umax = __uint_as_float(ob ^ ((ob >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+                    if (mykey == wkey) {  // exactly one lane (priorities are unique; an all-padding unit: lane with the largest ~p)
+                        FbCand c;
+                        c.key_lo = (unsigned)wkey; c.key_hi = (unsigned)(wkey >> 32);
+                        c.x = wx; c.y = wy; c.z = wz;
+                        c.k = wp == FB_NOPT ? 0 : k_of(wp);
+                        c.best = umax; c.pad = 0;
+                        cand[wave][u] = c;
+                    }
+                    if (lane == u) cmax = umax;
+                }
+            }
+            // wave candidate = best of the NU unit candidates (the untouched ones are still valid: D never grows, and a unit
+            // whose box the sample cannot reach keeps its maximum)
+            __builtin_amdgcn_wave_barrier();
+            const int w = lane & 15;
+            const FbCand c = cand[wave][w < NU ? w : 0];
+            const unsigned long long ckey = w < NU ? (((unsigned long long)c.key_hi << 32) | c.key_lo) : 0ull;
+            const unsigned long long rkey = row_umax64(ckey);
+            const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rkey, 15);
+            const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rkey >> 32), 15);
+            const unsigned long long gkey = ((unsigned long long)rhi << 32) | rlo;
+            if (lane < 16 && ckey == gkey && w < NU) {  // one lane (keys are unique)
+                FpsSlot sl;
+                sl.key_lo = c.key_lo; sl.key_hi = c.key_hi; sl.x = c.x; sl.y = c.y; sl.z = c.z; sl.k = c.k; sl.pad0 = 0; sl.pad1 = 0;
+                buf[wave] = sl;
+                cached[wave] = sl;
+            }
+            other_stale = true;
+        } else if (other_stale) {
+            if (lane == 0) buf[wave] = cached[wave];
+            other_stale = false;
+        }
+        __syncthreads();
+        const int w = lane & 15;
+        const FpsSlot sl = buf[w];
+        const unsigned long long skey = ((unsigned long long)sl.key_hi << 32) | sl.key_lo;
+        const unsigned long long rkey = row_umax64(skey);
+        const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rkey, 15);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rkey >> 32), 15);
+        const unsigned long long gkey = ((unsigned long long)rhi << 32) | rlo;
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(skey == gkey);
+        const int src = __builtin_ctzll(hit);
+        x1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.x), src));
+        y1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.y), src));
+        z1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sl.z), src));
+        const int win_k = __builtin_amdgcn_readlane(sl.k, src);
+        if (tid == 0) out[j] = win_k;
+    }
+    // temp is an in/out argument: hand the final running minima back
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pr = __float_as_int(mine[u * FB_UNIT + s].w);
+            if (pr != FB_NOPT) temp[k_of(pr)] = D[u * 4 + s];
+        }
+}
+
 template <int T>
 static bool launch_fps_t(int ppt_needed, int nclouds, const FpsArgs &A, hipStream_t st) {
     if (ppt_needed <= 1) hipLaunchKernelGGL((fps_kernel<T, 1>), dim3(nclouds), dim3(T), 0, st, A);
@@ -682,4 +879,31 @@ extern "C" __attribute__((visibility("default"))) int mgar_fps_batch_perm(int b,
     else if (ppt <= 8) hipLaunchKernelGGL((fps_pruned_kernel<8>), dim3(b), dim3(1024), 0, st, A, perm);
     else hipLaunchKernelGGL((fps_pruned_kernel<16>), dim3(b), dim3(1024), 0, st, A, perm);
     return check_launch("fps_batch_perm: launch failed");
+}
+
+// Clouds of 16 385 .. 65 536 points, any permutation `perm` (a Morton order is fast): see fps_bucket_kernel.
+// workspace: mgar_fps_batch_buckets_workspace_floats(b, n) floats, 16-byte aligned.
+extern "C" __attribute__((visibility("default"))) long long mgar_fps_batch_buckets_workspace_floats(int b, int n) {
+    if (b < 0 || n < 0) return -1;
+    const int cap = n <= 32768 ? 32768 : 65536;
+    return (long long)b * cap * 4;
+}
+extern "C" __attribute__((visibility("default"))) int mgar_fps_batch_buckets(int b, int n, int m, const float *points, float *temp,
+                                                                            const int *perm, float *workspace, int *idx, void *stream) {
+    MGAR_REQUIRE(b >= 0 && n >= 0 && m >= 0, "fps_batch_buckets: negative size");
+    if (b == 0 || m == 0) return MGAR_OK;
+    MGAR_REQUIRE(points && temp && idx && perm && workspace, "fps_batch_buckets: null pointer");
+    if (n <= 16384 || n > 65536 || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+        set_error("fps_batch_buckets: needs 16384 < n <= 65536 and a 16-byte aligned workspace (smaller clouds: mgar_fps_batch_perm)");
+        return MGAR_EUNSUPPORTED;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int cap = n <= 32768 ? 32768 : 65536;
+    FpsArgs A{0, n, m, 10, points, temp, nullptr, idx, nullptr};
+    KtScope kt(KT_FPS, st, (double)b * (12.0 * n + 4.0 * m), 8.0 * b * ((double)m - 1) * n);
+    float4 *sorted = reinterpret_cast<float4 *>(workspace);
+    hipLaunchKernelGGL(fps_bucket_prep_kernel, dim3(ceil_div(cap / 4, 256), b), dim3(256), 0, st, points, perm, n, cap, sorted);
+    if (cap == 32768) hipLaunchKernelGGL((fps_bucket_kernel<8>), dim3(b), dim3(1024), 0, st, A, sorted, cap);
+    else hipLaunchKernelGGL((fps_bucket_kernel<16>), dim3(b), dim3(1024), 0, st, A, sorted, cap);
+    return check_launch("fps_batch_buckets: launch failed");
 }

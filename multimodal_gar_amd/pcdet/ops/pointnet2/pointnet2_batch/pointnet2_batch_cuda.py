@@ -64,6 +64,17 @@ def farthest_point_sampling_pruned_wrapper(b, n, m, points, temp, idx):
     return 1
 
 
+def farthest_point_sampling_buckets_wrapper(b, n, m, points, temp, idx):
+    """Same result again for clouds of 16 385 .. 65 536 points (csrc/fps.hip, fps_bucket_kernel): pruning per 256-point unit."""
+    import torch
+    codes = torch.empty((b, n), dtype=torch.int32, device=points.device)
+    L.call("mgar_morton_codes", b, n, L.fptr(points), L.iptr(codes), L.stream_of(points))
+    perm = torch.sort(codes, dim=1).indices.int()
+    ws = torch.empty((L.raw("mgar_fps_batch_buckets_workspace_floats", b, n),), dtype=torch.float32, device=points.device)
+    L.call("mgar_fps_batch_buckets", b, n, m, L.fptr(points), L.fptr(temp), L.iptr(perm), L.fptr(ws), L.iptr(idx), L.stream_of(points))
+    return 1
+
+
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     L.call("mgar_three_nn_batch", b, n, m, L.fptr(unknown), L.fptr(known), L.fptr(dist2), L.iptr(idx),
            L.stream_of(unknown))

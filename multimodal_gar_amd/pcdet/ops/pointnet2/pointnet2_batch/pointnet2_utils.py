@@ -40,6 +40,8 @@ class FarthestPointSampling(Function):
         running_min = _new(xyz, (batch, n_pts), torch.float32, 1e10)
         if xyz.is_cuda and PRUNED_FPS_MIN_POINTS <= n_pts <= 16384 and hasattr(pointnet2, "farthest_point_sampling_pruned_wrapper"):
             pointnet2.farthest_point_sampling_pruned_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
+        elif xyz.is_cuda and 16384 < n_pts <= 65536 and hasattr(pointnet2, "farthest_point_sampling_buckets_wrapper"):
+            pointnet2.farthest_point_sampling_buckets_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
         else:
             pointnet2.farthest_point_sampling_wrapper(batch, n_pts, npoint, xyz, running_min, idx)
         ctx.mark_non_differentiable(idx)
