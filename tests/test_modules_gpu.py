@@ -69,11 +69,11 @@ def test_sa_msg_and_fp_modules_batch():
     for a, b in zip(go, co):
         close(a, b)
     for a, b in zip(gg, cg):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
     known = xyz[:, :100].contiguous(); kf = torch.randn(2, 12, 100); uf = torch.randn(2, 7, 1024)
     (go, gg), (co, cg) = run_both(lambda: M.PointnetFPModule(mlp=[19, 32, 16]), [(xyz, False), (known, False), (uf, True), (kf, True)])
     for a, b in zip(go + gg, co + cg):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
 
 
 def test_stack_sa_and_fp_modules():
@@ -88,12 +88,12 @@ def test_stack_sa_and_fp_modules():
                                   [(xyz, False), (cnt, False), (new_xyz, False), (ncnt, False), (feats, True)])
     close(go[1], co[1])
     for a, b in zip(gg, cg):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
     kf = torch.randn(111, 6)
     (go, gg), (co, cg) = run_both(lambda: M.StackPointnetFPModule(mlp=[15, 20]),
                                   [(xyz, False), (cnt, False), (new_xyz, False), (ncnt, False), (feats, True), (kf, True)])
     for a, b in zip(go + gg, co + cg):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
 
 
 def test_voxel_rcnn_route_detector():
@@ -135,7 +135,7 @@ def test_clip_model_forward_gpu_vs_cpu_backend():
         got = gm(gb)
     assert len(got) == 16
     for a, b in zip(got, want):
-        close(a, b, rtol=5e-4, atol=1e-5)
+        close(a, b, rtol=1e-4, atol=1e-5)
 
 
 def test_clip_model_train_mode_several_clips_gpu_vs_cpu_backend():
@@ -162,7 +162,7 @@ def test_clip_model_train_mode_several_clips_gpu_vs_cpu_backend():
     torch.cuda.synchronize()
     assert len(got) == 16
     for a, b in zip(got, want):
-        close(a, b, rtol=2e-3, atol=1e-5)      # train-mode BatchNorm over few samples amplifies fp32 rounding
+        close(a, b, rtol=2e-4, atol=1e-5)      # train-mode BatchNorm over few samples amplifies fp32 rounding: measured <= 6.4e-5
     # the whole coordinate-only part of the trunk (every level's FPS, ball queries, 3-NN weights) issued ahead on a third
     # stream: the same numbers, bit for bit (pcdet/models/backbones_3d/pointnet2_backbone.py: PointNet2MSG.geometry)
     assert gm.geometry_ahead == "fps1"
@@ -217,7 +217,7 @@ def test_gar_fusion_all_forward_reference_call_shape(route):
         got = gnet(tuple(gb))
     assert len(got) == 16 and got[0].shape == (1, 6, 6) and got[-1].shape == (1, 1)
     for a, b in zip(got, want):
-        close(a, b, rtol=5e-4, atol=1e-5)
+        close(a, b, rtol=1e-4, atol=1e-5)
 
 
 def test_social_grouping_model_forward():
@@ -236,7 +236,7 @@ def test_social_grouping_model_forward():
     with torch.no_grad():
         got = gnet(tuple(gb))
     assert got.shape == (4, 4) and torch.allclose(torch.diagonal(got), torch.ones(4, device="cuda"))
-    close(got, want, rtol=5e-4)
+    close(got, want, rtol=1e-4)
 
 
 def test_project_then_group_path_equals_reference_chain():
@@ -254,7 +254,7 @@ def test_project_then_group_path_equals_reference_chain():
     for a, b in zip(go, co):
         close(a, b)
     for a, b in zip(gg, cg):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
     sx = xyz.reshape(-1, 3)
     cnt = torch.tensor([900, 900], dtype=torch.int32)
     new_xyz = torch.cat([sx[:70], sx[900:990] + 0.05, torch.tensor([[500., 500., 500.]])])
@@ -264,7 +264,7 @@ def test_project_then_group_path_equals_reference_chain():
                                   [(sx, False), (cnt, False), (new_xyz, False), (ncnt, False), (sf, True)])
     close(go[1], co[1])
     for a, b in zip(gg, cg):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
 
 
 def test_stack_sa_msg_channel_major_features_equal_stacked_rows():
@@ -291,9 +291,9 @@ def test_stack_sa_msg_channel_major_features_equal_stacked_rows():
         fgrads.append(f.grad if cm else f.grad.view(3, 800, 40).permute(0, 2, 1))
         pgrads.append([p.grad for p in m.parameters()])
     close(outs[0], outs[1])
-    close(fgrads[0], fgrads[1], rtol=5e-4)
+    close(fgrads[0], fgrads[1], rtol=1e-4)
     for a, b in zip(*pgrads):
-        close(a, b, rtol=5e-4)
+        close(a, b, rtol=1e-4)
 
 
 def test_train_step_hip_graph_matches_eager():

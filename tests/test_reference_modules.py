@@ -84,4 +84,4 @@ def test_module_on_oracle_backend_matches_reference_module(case):
 def test_module_on_hip_kernels_matches_reference_module(case):
     m, args, ins, y = _run(case, "cuda")
     torch.cuda.synchronize()
-    _check(case, m, args, ins, y, rtol=5e-4)     # fused BN / MFMA summation orders, float-atomic scatters
+    _check(case, m, args, ins, y, rtol=1e-4)     # north_star's bound (round 2: 5e-4; measured margins <= 2.3e-5, round 3)

@@ -66,8 +66,14 @@ def main():
     torch.cuda.synchronize()
     names = {id(m): n for n, m in step.module.named_modules()}
     census = Census(names, args.depth)
-    pre = torch.nn.modules.module.register_module_forward_pre_hook(lambda m, a: census.stack.append(names.get(id(m), type(m).__name__)))
-    post = torch.nn.modules.module.register_module_forward_hook(lambda m, a, o: census.stack.pop() if census.stack else None)
+    def enter(m, a):
+        census.stack.append(names.get(id(m), type(m).__name__))
+
+    def leave(m, a, o):     # must return None: a returned value would replace the module's output
+        if census.stack:
+            census.stack.pop()
+    pre = torch.nn.modules.module.register_module_forward_pre_hook(enter)
+    post = torch.nn.modules.module.register_module_forward_hook(leave)
     real_call = L.call
 
     def counting_call(name, *a):
