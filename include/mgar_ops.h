@@ -112,6 +112,20 @@ long long mgar_fps_batch_buckets_workspace_floats(int b, int n);
 int mgar_fps_batch_buckets(int b, int n, int m, const float *points, float *temp, const int *perm, float *workspace, int *idx,
                            void *stream);
 
+/* Ball query through a uniform cell grid (csrc/ball_query_grid.hip; round 3): the rows of mgar_ball_query_batch / _stack, bit
+ * for bit, for queries that rarely fill their balls (the RoI-grid points: every scan of the plain kernel runs to the end of
+ * the cloud).  mgar_point_grid_build bins the points of B clouds once (batch layout: n_batch > 0, xyz_batch_cnt NULL; stack
+ * layout: n_batch 0, xyz_batch_cnt (B) on the device; n_total = rows of xyz; cell = cell edge, enlarged per cloud until the
+ * grid has at most 32 768 cells) into `workspace` (mgar_point_grid_workspace_bytes(B, n_total) bytes, 16-byte aligned), which
+ * the queries take as `grid` for as long as xyz is unchanged.  nsample <= 64 (MGAR_EUNSUPPORTED above: use the scan kernels). */
+long long mgar_point_grid_workspace_bytes(int B, long long n_total);
+int mgar_point_grid_build(int B, int n_batch, long long n_total, const float *xyz, const int *xyz_batch_cnt, float cell,
+                          void *workspace, void *stream);
+int mgar_ball_query_grid_batch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const void *grid, int *idx,
+                               void *stream);
+int mgar_ball_query_grid_stack(int B, int M, long long n_total, float radius, int nsample, const float *new_xyz,
+                               const int *new_xyz_batch_cnt, const void *grid, int *idx, void *stream);
+
 /* three_nn_wrapper   pointnet2_api.cpp:21;  kernel interpolate_gpu.cu:16-59
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3). */
 int mgar_three_nn_batch(int b, int n, int m, const float *unknown, const float *known,

@@ -33,6 +33,10 @@ _PROTOS = {
     "mgar_fps_batch": [_I, _I, _I, _P, _P, _P, _P],
     "mgar_morton_codes": [_I, _I, _P, _P, _P],
     "mgar_fps_batch_perm": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_point_grid_workspace_bytes": [_I, ctypes.c_longlong],
+    "mgar_point_grid_build": [_I, _I, ctypes.c_longlong, _P, _P, _F, _P, _P],
+    "mgar_ball_query_grid_batch": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
+    "mgar_ball_query_grid_stack": [_I, _I, ctypes.c_longlong, _F, _I, _P, _P, _P, _P, _P],
     "mgar_fps_batch_buckets": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_fps_batch_buckets_workspace_floats": [_I, _I],
     "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
@@ -147,7 +151,7 @@ _LONGLONG_RESULTS = frozenset((
     "mgar_query_group_stack_inverse_items", "mgar_query_group_stack_inverse_workspace_ints", "mgar_bn_cl_workspace_floats",
     "mgar_bn_stats_from_partials_workspace_floats", "mgar_voxel_roi_pool_stats_workspace_doubles",
     "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints", "mgar_gatv2_bwd_workspace_floats",
-    "mgar_fps_batch_buckets_workspace_floats"))
+    "mgar_fps_batch_buckets_workspace_floats", "mgar_point_grid_workspace_bytes"))
 
 _fns = {}
 for _name, _args in _PROTOS.items():

@@ -1,0 +1,363 @@
+// ball_query_grid.hip -- ball query through a uniform cell grid (batch + stack layouts) for gfx950.
+//
+// Same results as csrc/ball_query.hip (reference pointnet2_batch/src/ball_query_gpu.cu:15-51, pointnet2_stack/src/
+// ball_query_gpu.cu:16-66), bit for bit: the first nsample indices k in ASCENDING order with d2 < r2, the row padded with
+// its first hit, untouched (batch) / idx[0] = -1 (stack) when the ball is empty.
+//
+// The scan kernel tests every (query, point) pair -- 7 VALU each, at the vector peak already -- which is the right thing
+// where rows fill up and the scan stops early (the trunk's FPS centres).  The RoI-grid queries rarely fill their balls:
+// every scan runs to the end of the cloud, 1.1 ms per radius at config c3 and 26 ms at c5 (128 actors x 65 536 points).
+// Here the points of a cloud are binned once into cells of edge h (counting sort with integer atomics; the order inside a
+// cell is irrelevant), a query visits only the cells its ball can touch, and keeps the nsample SMALLEST hit indices in a
+// sorted register list (min / max insertion, 2 VALU per slot and hit) -- "first nsample in index order" is a property of
+// the hit SET, so any visiting order gives the reference's row.  ~130 candidates per query instead of 16 384 at c3.
+//   * the distance test is the same expression on the same operands (d2_of(q - p), strict <);
+//   * the cell range of a query is computed from q -+ r(1 + 1e-5) with the same monotone fp32 map that bins the points,
+//     so no point inside the ball can fall outside the visited range;
+//   * cells are x-fastest: the cells (cz, cy, x0..x1) of a query are ONE contiguous run of the sorted point array.
+#include "common.hpp"
+
+namespace mgar {
+
+constexpr int PG_MAX_CELLS = 32768;   // cells per cloud (the cell edge grows until the grid fits)
+constexpr int PG_GEOM_INTS = 16;      // per cloud: lo[3], inv_h, dim[3], ncell, pstart, n, h
+constexpr int BQG_THREADS = 256;
+constexpr int BQG_ROW_STRIDE = BQG_THREADS + 1;
+
+struct PgLayout {   // byte offsets inside the workspace (all 16-byte aligned)
+    size_t geom, cell_start, cursor, cell_of, sorted, total;
+};
+__host__ __device__ inline size_t pg_align(size_t v) { return (v + 15) & ~(size_t)15; }
+static PgLayout pg_layout(int B, long long n_total) {
+    PgLayout l;
+    size_t o = 0;
+    l.geom = o; o = pg_align(o + (size_t)B * PG_GEOM_INTS * 4);
+    l.cell_start = o; o = pg_align(o + (size_t)B * (PG_MAX_CELLS + 1) * 4);
+    l.cursor = o; o = pg_align(o + (size_t)B * PG_MAX_CELLS * 4);
+    l.cell_of = o; o = pg_align(o + (size_t)n_total * 4);
+    l.sorted = o; o = pg_align(o + (size_t)n_total * 16);
+    l.total = o;
+    return l;
+}
+
+struct PgGeom {
+    float lo[3];
+    float inv_h;
+    int dim[3];
+    int ncell, pstart, n;
+    float h;
+    int pad[5];
+};
+static_assert(sizeof(PgGeom) == PG_GEOM_INTS * 4, "PgGeom layout");
+
+// the one map from a coordinate to a cell index (monotone non-decreasing in v: fp32 subtract, multiply by a positive constant, floor)
+__device__ __forceinline__ int pg_cell(float v, float lo, float inv_h) {
+    const float t = floorf((v - lo) * inv_h);
+    return (int)fminf(fmaxf(t, -1048576.f), 1048576.f);
+}
+
+// K1: per cloud -- start row, bounding box, grid dimensions; zero the cell counters.  grid (B), block 1024
+__global__ __launch_bounds__(1024) void pg_geom_kernel(int n_batch, const float *__restrict__ xyz, const int *__restrict__ xyz_batch_cnt,
+                                                       float cell, PgGeom *__restrict__ geom, int *__restrict__ cursor) {
+    __shared__ float red[6][16];
+    const int b = blockIdx.x;
+    int pstart, n;
+    if (xyz_batch_cnt) {
+        pstart = 0;
+        for (int i = 0; i < b; ++i) pstart += xyz_batch_cnt[i];
+        n = xyz_batch_cnt[b];
+    } else {
+        pstart = b * n_batch;
+        n = n_batch;
+    }
+    const float *P = xyz + (size_t)pstart * 3;
+    const float inf = __builtin_inff();
+    float lo[3] = {inf, inf, inf}, hi[3] = {-inf, -inf, -inf};
+    for (int k = threadIdx.x; k < n; k += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { const float v = P[k * 3 + a]; lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float l = -wave_max(-lo[a]), h = wave_max(hi[a]);
+        if (lane == 0) { red[a][wave] = l; red[3 + a][wave] = h; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float l = inf, h = -inf;
+        for (int w = 0; w < 16; ++w) { l = fminf(l, red[a][w]); h = fmaxf(h, red[3 + a][w]); }
+        lo[a] = n > 0 ? l : 0.f;
+        hi[a] = n > 0 ? h : 0.f;
+    }
+    // cell edge: the caller's, enlarged until the grid has at most PG_MAX_CELLS cells (dim = floor(ext / h) + 1 per axis:
+    // every point's cell index is then inside [0, dim) without clamping)
+    float h = cell;
+    int d[3];
+    for (int it = 0; it < 200; ++it) {
+        const float ih = 1.f / h;
+        long long c = 1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { d[a] = pg_cell(hi[a], lo[a], ih) + 1; c *= d[a]; }   // cell(v) <= cell(hi) = dim - 1 for every point v
+        if (c <= PG_MAX_CELLS) break;
+        h *= 1.25f;
+    }
+    const int ncell = d[0] * d[1] * d[2];
+    if (threadIdx.x == 0) {
+        PgGeom g;
+        g.lo[0] = lo[0]; g.lo[1] = lo[1]; g.lo[2] = lo[2];
+        g.inv_h = 1.f / h; g.h = h;
+        g.dim[0] = d[0]; g.dim[1] = d[1]; g.dim[2] = d[2];
+        g.ncell = ncell; g.pstart = pstart; g.n = n;
+        for (int i = 0; i < 5; ++i) g.pad[i] = 0;
+        geom[b] = g;
+    }
+    int *cnt = cursor + (size_t)b * PG_MAX_CELLS;
+    for (int c = threadIdx.x; c < ncell; c += 1024) cnt[c] = 0;
+}
+
+// cloud of global point row p (stack layout: binary search over the clouds' start rows)
+__device__ __forceinline__ int pg_cloud_of(long long p, int B, int n_batch, const PgGeom *geom) {
+    if (n_batch > 0) return (int)(p / n_batch);
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (geom[mid].pstart <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// K2: cell of every point + histogram.  grid over all points, block 256
+__global__ __launch_bounds__(256) void pg_count_kernel(long long n_total, int B, int n_batch, const float *__restrict__ xyz,
+                                                       const PgGeom *__restrict__ geom, int *__restrict__ cursor, int *__restrict__ cell_of) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_total) return;
+    const int b = pg_cloud_of(p, B, n_batch, geom);
+    const PgGeom g = geom[b];
+    if (p >= (long long)g.pstart + g.n) return;   // stack layout: rows beyond the last cloud's count
+    const int cx = pg_cell(xyz[p * 3 + 0], g.lo[0], g.inv_h), cy = pg_cell(xyz[p * 3 + 1], g.lo[1], g.inv_h);
+    const int cz = pg_cell(xyz[p * 3 + 2], g.lo[2], g.inv_h);
+    const int c = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    cell_of[p] = c;
+    atomicAdd(cursor + (size_t)b * PG_MAX_CELLS + c, 1);
+}
+
+// K3: exclusive scan of a cloud's histogram -> cell_start (ncell + 1), cursor = cell_start.  grid (B), block 1024
+__global__ __launch_bounds__(1024) void pg_scan_kernel(const PgGeom *__restrict__ geom, int *__restrict__ cursor, int *__restrict__ cell_start) {
+    __shared__ int part[1024];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int ncell = geom[b].ncell;
+    int *cnt = cursor + (size_t)b * PG_MAX_CELLS;
+    int *start = cell_start + (size_t)b * (PG_MAX_CELLS + 1);
+    constexpr int PER = PG_MAX_CELLS / 1024;   // 32 consecutive cells per thread
+    int v[PER], s = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const int c = t * PER + i; v[i] = c < ncell ? cnt[c] : 0; s += v[i]; }
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1 024 partial sums
+        const int add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = t * PER + i;
+        if (c < ncell) { start[c] = run; cnt[c] = run; }
+        run += v[i];
+    }
+    if (t == 1023) start[ncell] = part[1023];
+}
+
+// K4: scatter {x, y, z, k} into cell order (k = index inside the cloud).  grid over all points, block 256
+__global__ __launch_bounds__(256) void pg_scatter_kernel(long long n_total, int B, int n_batch, const float *__restrict__ xyz,
+                                                         const PgGeom *__restrict__ geom, const int *__restrict__ cell_of,
+                                                         int *__restrict__ cursor, float4 *__restrict__ sorted) {
+    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_total) return;
+    const int b = pg_cloud_of(p, B, n_batch, geom);
+    const int pstart = geom[b].pstart, n = geom[b].n;
+    if (p >= (long long)pstart + n) return;
+    const int pos = atomicAdd(cursor + (size_t)b * PG_MAX_CELLS + cell_of[p], 1);
+    sorted[(size_t)pstart + pos] = make_float4(xyz[p * 3 + 0], xyz[p * 3 + 1], xyz[p * 3 + 2], __int_as_float((int)(p - pstart)));
+}
+
+// ---- the query --------------------------------------------------------------------------------------------------------
+template <bool STACK, int NS>
+__global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int B, int m_batch, float radius, float radius2, int nsample,
+                                                                      const float *__restrict__ new_xyz,
+                                                                      const int *__restrict__ new_xyz_batch_cnt,
+                                                                      const PgGeom *__restrict__ geom, const int *__restrict__ cell_start,
+                                                                      const float4 *__restrict__ sorted, int *__restrict__ idx) {
+    extern __shared__ int lds[];  // [nsample][257] rows, then [256] counts (coalesced write-out, as csrc/ball_query.hip)
+    int *rows = lds;
+    int *cnts = lds + nsample * BQG_ROW_STRIDE;
+    int q0, q_end, bs;
+    if (STACK) {
+        int g = blockIdx.x, qs = 0;
+        bool found = false;
+        for (bs = 0; bs < B; ++bs) {
+            const int mi = new_xyz_batch_cnt[bs];
+            const int nb = (mi + BQG_THREADS - 1) / BQG_THREADS;
+            if (g < nb) { found = true; break; }
+            g -= nb;
+            qs += mi;
+        }
+        if (!found) return;
+        q0 = qs + g * BQG_THREADS;
+        q_end = qs + new_xyz_batch_cnt[bs];
+    } else {
+        bs = blockIdx.y;
+        q0 = bs * m_batch + blockIdx.x * BQG_THREADS;
+        q_end = (bs + 1) * m_batch;
+    }
+    const PgGeom g = geom[bs];
+    const int *__restrict__ start = cell_start + (size_t)bs * (PG_MAX_CELLS + 1);
+    const float4 *__restrict__ pts = sorted + g.pstart;
+    const int tid = threadIdx.x;
+    const int q = q0 + tid;
+    const bool valid = q < q_end;
+    int list[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) list[s] = 0x7FFFFFFF;
+    int cnt = 0;
+    if (valid && g.n > 0) {
+        const float qx = new_xyz[(size_t)q * 3 + 0], qy = new_xyz[(size_t)q * 3 + 1], qz = new_xyz[(size_t)q * 3 + 2];
+        const float rr = radius * 1.00001f + 1e-30f;   // the cell range may only be too wide, never too narrow
+        const int x0 = max(pg_cell(qx - rr, g.lo[0], g.inv_h), 0), x1 = min(pg_cell(qx + rr, g.lo[0], g.inv_h), g.dim[0] - 1);
+        const int y0 = max(pg_cell(qy - rr, g.lo[1], g.inv_h), 0), y1 = min(pg_cell(qy + rr, g.lo[1], g.inv_h), g.dim[1] - 1);
+        const int z0 = max(pg_cell(qz - rr, g.lo[2], g.inv_h), 0), z1 = min(pg_cell(qz + rr, g.lo[2], g.inv_h), g.dim[2] - 1);
+        if (x0 <= x1)
+            for (int cz = z0; cz <= z1; ++cz)
+                for (int cy = y0; cy <= y1; ++cy) {
+                    const int base = (cz * g.dim[1] + cy) * g.dim[0];
+                    const int e = start[base + x1 + 1];
+                    for (int p = start[base + x0]; p < e; ++p) {
+                        const float4 v = pts[p];
+                        const float d2 = d2_of(qx - v.x, qy - v.y, qz - v.z);
+                        if (d2 < radius2) {
+                            int nv = __float_as_int(v.w);
+                            ++cnt;
+                            if (nv < list[NS - 1]) {   // once the list is full of small indices most hits stop here
+#pragma unroll
+                                for (int s = 0; s < NS; ++s) {   // sorted insertion: list keeps the NS smallest indices, ascending
+                                    const int a = list[s];
+                                    list[s] = min(a, nv);
+                                    nv = max(a, nv);
+                                }
+                            }
+                        }
+                    }
+                }
+    }
+    const int c = min(cnt, nsample);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (s < c) rows[s * BQG_ROW_STRIDE + tid] = list[s];
+    cnts[tid] = valid ? c : -1;
+    __syncthreads();
+    const int nq = min(BQG_THREADS, q_end - q0);
+    const int total = nq * nsample;
+    int *out = idx + (size_t)q0 * nsample;
+    for (int e = tid; e < total; e += BQG_THREADS) {
+        const int ql = e / nsample, s = e - ql * nsample;
+        const int cc = cnts[ql];
+        if (cc > 0) {
+            out[e] = rows[(s < cc ? s : 0) * BQG_ROW_STRIDE + ql];
+        } else if (STACK && s == 0) {
+            out[e] = -1;
+        }
+    }
+}
+
+}  // namespace mgar
+
+using namespace mgar;
+
+#define BQG_API extern "C" __attribute__((visibility("default")))
+
+BQG_API long long mgar_point_grid_workspace_bytes(int B, long long n_total) {
+    if (B < 0 || n_total < 0) return -1;
+    return (long long)pg_layout(B, n_total).total;
+}
+
+// Bins the points of B clouds into cells of edge `cell` (enlarged per cloud until it has at most 32 768 cells).
+// Batch layout: n_batch > 0 points per cloud, xyz_batch_cnt == NULL; stack layout: n_batch == 0, xyz_batch_cnt (B) on the device.
+// n_total = rows of xyz.  workspace: mgar_point_grid_workspace_bytes(B, n_total) bytes, 16-byte aligned; it is what
+// mgar_ball_query_grid_* take, valid for as long as xyz is unchanged.
+BQG_API int mgar_point_grid_build(int B, int n_batch, long long n_total, const float *xyz, const int *xyz_batch_cnt, float cell,
+                                  void *workspace, void *stream) {
+    MGAR_REQUIRE(B >= 0 && n_batch >= 0 && n_total >= 0 && cell > 0.f, "point_grid_build: bad sizes");
+    if (B == 0 || n_total == 0) return MGAR_OK;
+    MGAR_REQUIRE(xyz && workspace && (n_batch > 0 || xyz_batch_cnt), "point_grid_build: null pointer");
+    MGAR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "point_grid_build: workspace must be 16-byte aligned");
+    MGAR_REQUIRE(n_batch == 0 || (long long)B * n_batch == n_total, "point_grid_build: batch layout needs n_total == B * n");
+    MGAR_REQUIRE(n_total / 256 < 2147483647LL, "point_grid_build: too many points");
+    hipStream_t st = (hipStream_t)stream;
+    const PgLayout l = pg_layout(B, n_total);
+    char *ws = (char *)workspace;
+    PgGeom *geom = (PgGeom *)(ws + l.geom);
+    int *cell_start = (int *)(ws + l.cell_start), *cursor = (int *)(ws + l.cursor), *cell_of = (int *)(ws + l.cell_of);
+    float4 *sorted = (float4 *)(ws + l.sorted);
+    // points read twice (bounding box, binning) + 4 B cell id written and read + the 16-byte sorted record written
+    KtScope kt(KT_POINT_GRID, st, (double)n_total * (24.0 + 8.0 + 16.0));
+    const int blocks = (int)((n_total + 255) / 256);
+    hipLaunchKernelGGL(pg_geom_kernel, dim3(B), dim3(1024), 0, st, n_batch, xyz, n_batch > 0 ? nullptr : xyz_batch_cnt, cell, geom, cursor);
+    hipLaunchKernelGGL(pg_count_kernel, dim3(blocks), dim3(256), 0, st, n_total, B, n_batch, xyz, geom, cursor, cell_of);
+    hipLaunchKernelGGL(pg_scan_kernel, dim3(B), dim3(1024), 0, st, geom, cursor, cell_start);
+    hipLaunchKernelGGL(pg_scatter_kernel, dim3(blocks), dim3(256), 0, st, n_total, B, n_batch, xyz, geom, cell_of, cursor, sorted);
+    return check_launch("point_grid_build: launch failed");
+}
+
+template <bool STACK>
+static int bqg_launch(int B, int m_batch, long long m_total, long long n_total, float radius, int nsample, const float *new_xyz,
+                      const int *new_cnt, const void *workspace, int *idx, void *stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const PgLayout l = pg_layout(B, n_total);
+    const char *ws = (const char *)workspace;
+    const PgGeom *geom = (const PgGeom *)(ws + l.geom);
+    const int *cell_start = (const int *)(ws + l.cell_start);
+    const float4 *sorted = (const float4 *)(ws + l.sorted);
+    const size_t lds = ((size_t)nsample * BQG_ROW_STRIDE + BQG_THREADS) * sizeof(int);
+    dim3 grid = STACK ? dim3((unsigned)((m_total + BQG_THREADS - 1) / BQG_THREADS + B)) : dim3(ceil_div(m_batch, BQG_THREADS), B);
+    // 12 N + 12 M + 4 M nsample; the pair tests depend on the data (credited by the caller)
+    KtScope kt(KT_BALL_QUERY_GRID, st, 12.0 * (double)n_total + (double)m_total * (12.0 + 4.0 * nsample));
+#define BQG_GO(NS)                                                                                                             \
+    do {                                                                                                                       \
+        if (lds > 65536) (void)hipFuncSetAttribute((const void *)ball_query_grid_kernel<STACK, NS>,                             \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((ball_query_grid_kernel<STACK, NS>), grid, dim3(BQG_THREADS), lds, st, B, m_batch, radius, radius * radius, \
+                           nsample, new_xyz, new_cnt, geom, cell_start, sorted, idx);                                           \
+    } while (0)
+    if (nsample <= 16) BQG_GO(16);
+    else if (nsample <= 32) BQG_GO(32);
+    else BQG_GO(64);
+#undef BQG_GO
+    return check_launch("ball_query_grid: launch failed");
+}
+
+// ball query of mgar_ball_query_batch / _stack through the grid of mgar_point_grid_build (same xyz, same B / n).  nsample <= 64.
+BQG_API int mgar_ball_query_grid_batch(int b, int n, int m, float radius, int nsample, const float *new_xyz, const void *grid, int *idx,
+                                       void *stream) {
+    MGAR_REQUIRE(b >= 0 && n >= 0 && m >= 0 && radius >= 0.f, "ball_query_grid_batch: bad sizes");
+    if (nsample < 1 || nsample > 64) { set_error("ball_query_grid: nsample outside [1, 64] (use mgar_ball_query_batch)"); return MGAR_EUNSUPPORTED; }
+    if (b == 0 || m == 0) return MGAR_OK;
+    MGAR_REQUIRE(new_xyz && idx && (grid || n == 0), "ball_query_grid_batch: null pointer");
+    if (n == 0) return MGAR_OK;
+    return bqg_launch<false>(b, m, (long long)b * m, (long long)b * n, radius, nsample, new_xyz, nullptr, grid, idx, stream);
+}
+BQG_API int mgar_ball_query_grid_stack(int B, int M, long long n_total, float radius, int nsample, const float *new_xyz,
+                                       const int *new_xyz_batch_cnt, const void *grid, int *idx, void *stream) {
+    MGAR_REQUIRE(B >= 0 && M >= 0 && n_total >= 0 && radius >= 0.f, "ball_query_grid_stack: bad sizes");
+    if (nsample < 1 || nsample > 64) { set_error("ball_query_grid: nsample outside [1, 64] (use mgar_ball_query_stack)"); return MGAR_EUNSUPPORTED; }
+    if (B == 0 || M == 0) return MGAR_OK;
+    MGAR_REQUIRE(new_xyz && new_xyz_batch_cnt && idx, "ball_query_grid_stack: null pointer");
+    if (n_total == 0) {   // every ball is empty
+        set_error("ball_query_grid_stack: empty point set (use mgar_ball_query_stack)");
+        return MGAR_EUNSUPPORTED;
+    }
+    MGAR_REQUIRE(grid, "ball_query_grid_stack: null grid");
+    return bqg_launch<true>(B, 0, M, n_total, radius, nsample, new_xyz, new_xyz_batch_cnt, grid, idx, stream);
+}

@@ -9,16 +9,38 @@ into caller-allocated tensors, as in the reference.  Returns 1 like the referenc
 from ..... import _lib as L
 
 
-def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+def ball_query_scan_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    """The scan kernel (csrc/ball_query.hip): every (query, point) pair, early exit once the rows of a wave are full."""
     L.call("mgar_ball_query_batch", b, n, m, float(radius), nsample, L.fptr(new_xyz), L.fptr(xyz), L.iptr(idx),
            L.stream_of(xyz))
     return 1
 
 
+def ball_query_grid_wrapper(b, n, m, radius, nsample, new_xyz, grid, idx):
+    """The same rows through a uniform cell grid over the cloud (csrc/ball_query_grid.hip); grid: point_grid.PointGrid."""
+    L.call("mgar_ball_query_grid_batch", b, n, m, float(radius), nsample, L.fptr(new_xyz), L.fptr(grid.ws), L.iptr(idx),
+           L.stream_of(new_xyz))
+    return 1
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    from ..... import point_grid as G
+    if G.wanted(n, [nsample]):
+        return ball_query_grid_wrapper(b, n, m, radius, nsample, new_xyz, G.PointGrid(xyz, G.cell_for([radius])), idx)
+    return ball_query_scan_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx)
+
+
 def ball_query_multi_wrapper(b, n, m, radii, nsamples, new_xyz, xyz, idx_list):
-    """Several (radius, nsample) pairs in one scan; idx_list[r] (b, m, nsamples[r]) as ball_query_wrapper fills it."""
+    """Several (radius, nsample) pairs over the same cloud and centres; idx_list[r] (b, m, nsamples[r]) as ball_query_wrapper
+    fills it.  Large clouds: one cell grid, one query per radius; otherwise all radii in one scan."""
+    from ..... import point_grid as G
+    if G.wanted(n, nsamples):
+        grid = G.PointGrid(xyz, G.cell_for(radii))
+        for r, ns, idx in zip(radii, nsamples, idx_list):
+            ball_query_grid_wrapper(b, n, m, r, ns, new_xyz, grid, idx)
+        return 1
     if len(radii) == 1:
-        return ball_query_wrapper(b, n, m, radii[0], nsamples[0], new_xyz, xyz, idx_list[0])
+        return ball_query_scan_wrapper(b, n, m, radii[0], nsamples[0], new_xyz, xyz, idx_list[0])
     fa, ia, pa = L.host_arrays(radii, nsamples, idx_list)
     L.call("mgar_ball_query_multi_batch", b, n, m, len(radii), fa, ia, L.fptr(new_xyz), L.fptr(xyz), pa, L.stream_of(xyz))
     return 1

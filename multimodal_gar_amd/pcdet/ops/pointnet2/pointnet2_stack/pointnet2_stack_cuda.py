@@ -14,17 +14,42 @@ def _note_pairs(kernel, cnt_a, cnt_b, scans=1):
         L.note_pair_tests(kernel, scans * float((cnt_a.double() * cnt_b.double()).sum().item()))
 
 
-def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+def ball_query_scan_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+    """The scan kernel (csrc/ball_query.hip): every (query, point) pair of a sample."""
     L.call("mgar_ball_query_stack", B, M, float(radius), nsample, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt),
            L.fptr(xyz), L.iptr(xyz_batch_cnt), L.iptr(idx), L.stream_of(xyz))
     _note_pairs("ball_query_kernel", new_xyz_batch_cnt, xyz_batch_cnt)
     return 1
 
 
+def ball_query_grid_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, grid, idx):
+    """The same rows through a uniform cell grid over the clouds (csrc/ball_query_grid.hip); grid: point_grid.PointGrid."""
+    L.call("mgar_ball_query_grid_stack", B, M, grid.n_total, float(radius), nsample, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt),
+           L.fptr(grid.ws), L.iptr(idx), L.stream_of(new_xyz))
+    return 1
+
+
+def ball_query_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx, grid=None):
+    """grid: a point_grid.PointGrid over (xyz, xyz_batch_cnt) built by the caller (several radii over one cloud set share it);
+    without one, large clouds get their own."""
+    from ..... import point_grid as G
+    if grid is None and B > 0 and M > 0 and xyz.is_cuda and G.wanted(xyz.shape[0] // max(B, 1), [nsample]):
+        grid = G.PointGrid(xyz, G.cell_for([radius]), xyz_batch_cnt.int())
+    if grid is not None and nsample <= G.MAX_NSAMPLE:
+        return ball_query_grid_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, grid, idx)
+    return ball_query_scan_wrapper(B, M, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+
+
 def ball_query_multi_wrapper(B, M, radii, nsamples, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_list):
     """Several (radius, nsample) pairs in one scan; idx_list[r] (M, nsamples[r]) as ball_query_wrapper fills it."""
+    from ..... import point_grid as G
+    if B > 0 and M > 0 and G.wanted(xyz.shape[0] // max(B, 1), nsamples):
+        grid = G.PointGrid(xyz, G.cell_for(radii), xyz_batch_cnt.int())
+        for r, ns, idx in zip(radii, nsamples, idx_list):
+            ball_query_grid_wrapper(B, M, r, ns, new_xyz, new_xyz_batch_cnt, grid, idx)
+        return 1
     if len(radii) == 1:
-        return ball_query_wrapper(B, M, radii[0], nsamples[0], new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_list[0])
+        return ball_query_scan_wrapper(B, M, radii[0], nsamples[0], new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx_list[0])
     fa, ia, pa = L.host_arrays(radii, nsamples, idx_list)
     L.call("mgar_ball_query_multi_stack", B, M, len(radii), fa, ia, L.fptr(new_xyz), L.iptr(new_xyz_batch_cnt), L.fptr(xyz),
            L.iptr(xyz_batch_cnt), pa, L.stream_of(xyz))

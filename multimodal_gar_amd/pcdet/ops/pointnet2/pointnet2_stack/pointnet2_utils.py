@@ -197,8 +197,17 @@ class _FusedQueryGroupProjMSG(Function):
         # the scans stop early -- the trunk's FPS centres: 2.56 vs 3.38 ms; the RoI grid points rarely fill their
         # smallest ball, every scan runs to the end of the cloud and the heavier per-pair path loses: 4.16 vs 3.51 ms.)
         idxs = [torch.zeros((n_query, ns), dtype=torch.int32, device=xyz.device) for ns in nsamples]
+        # round 3: large clouds are binned into a cell grid ONCE and every radius queries it (csrc/ball_query_grid.hip):
+        # ~130 candidates per query instead of the whole cloud
+        from ..... import point_grid as G
+        grid = None
+        if xyz.is_cuda and n_query > 0 and G.wanted(xyz.shape[0] // max(n_samples, 1), nsamples) and hasattr(pointnet2, "ball_query_grid_wrapper"):
+            grid = G.PointGrid(xyz, G.cell_for(radii), xyz_batch_cnt.int())
         for radius, nsample, idx in zip(radii, nsamples, idxs):
-            pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
+            if grid is not None:
+                pointnet2.ball_query_grid_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, grid, idx)
+            else:
+                pointnet2.ball_query_wrapper(n_samples, n_query, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx)
         rows_bwd = tuple(bool(r) and c <= 64 and zf.dtype == torch.float32 for r, c in zip(rows_bwd, chans))
         from .....bn_ops import stats_partial_buffer
         stats = []
