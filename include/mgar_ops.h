@@ -358,6 +358,12 @@ int mgar_bn_cl_train_stats(const float *x, int S, int R, int C, int per_sample, 
                            long long *num_batches_tracked, void *stream);
 int mgar_bn_cl_act_fwd(const float *x, int S, int R, int C, int per_sample, const float *mean, const float *invstd,
                        const float *gamma, const float *beta, int relu, float *y, int ldy, void *stream);
+/* BatchNorm1d(train) [+ ReLU] BACKWARD over row-major x, dy (rows, C) fp32 -- the sparse trunk's (N_active, C) features
+ * (pcdet/models/backbones_3d/spconv_backbone.py:8-27 post_act_block: BatchNorm1d + ReLU on .features); forward = the two entry
+ * points above with S = 1.  dx (rows, C), dgamma / dbeta (C) fully written.  workspace: mgar_bn_rows_bwd_workspace_floats. */
+long long mgar_bn_rows_bwd_workspace_floats(int rows, int C);
+int mgar_bn_rows_bwd(const float *dy, const float *x, int rows, int C, const float *mean, const float *invstd, const float *gamma,
+                     const float *beta, int relu, float *workspace, float *dgamma, float *dbeta, float *dx, void *stream);
 int mgar_bn_act_fwd_to_cl(const float *x, int S, int C, int R, int per_sample, const float *mean, const float *invstd,
                           const float *gamma, const float *beta, int relu, float *y, int ldy, void *stream);
 int mgar_maxpool3d_same_fwd_cl(const float *x, int N, int T, int H, int W, int C, int kt, int kh, int kw, int st, int sh, int sw,

@@ -85,6 +85,8 @@ _PROTOS = {
     "mgar_bn_cl_workspace_floats": [_I, _I, _I, _I],
     "mgar_bn_cl_train_stats": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P],
     "mgar_bn_cl_act_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
+    "mgar_bn_rows_bwd_workspace_floats": [_I, _I],
+    "mgar_bn_rows_bwd": [_P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P],
     "mgar_bn_act_fwd_to_cl": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _I, _P],
     "mgar_maxpool3d_same_fwd_cl": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_bn_act_small": [_P, _I, _I, _I, _I, _F, _F, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _LL, _P],
@@ -151,7 +153,8 @@ _LONGLONG_RESULTS = frozenset((
     "mgar_query_group_stack_inverse_items", "mgar_query_group_stack_inverse_workspace_ints", "mgar_bn_cl_workspace_floats",
     "mgar_bn_stats_from_partials_workspace_floats", "mgar_voxel_roi_pool_stats_workspace_doubles",
     "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints", "mgar_gatv2_bwd_workspace_floats",
-    "mgar_fps_batch_buckets_workspace_floats", "mgar_point_grid_workspace_bytes"))
+    "mgar_fps_batch_buckets_workspace_floats", "mgar_point_grid_workspace_bytes",
+    "mgar_bn_rows_bwd_workspace_floats"))
 
 _fns = {}
 for _name, _args in _PROTOS.items():

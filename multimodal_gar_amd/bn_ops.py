@@ -408,6 +408,51 @@ def bn_act_to_channels_last(x, bn, relu, per_sample):
     return y
 
 
+class _BnActRows(Function):
+    """y = [relu](batch_norm_train(x)) for ROW-MAJOR x (rows, C): the sparse trunk's features (csrc/channels_last.hpp)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, invstd, relu):
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        L.call("mgar_bn_cl_act_fwd", L.fptr(x), 1, rows, c, 0, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta), int(relu),
+               L.fptr(y), c, L.stream_of(x))
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        rows, c = x.shape
+        dy = dy.contiguous()
+        dx, dgamma, dbeta = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty((L.raw("mgar_bn_rows_bwd_workspace_floats", rows, c),), dtype=torch.float32, device=x.device)
+        L.call("mgar_bn_rows_bwd", L.fptr(dy), L.fptr(x), rows, c, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+               int(ctx.relu), L.fptr(ws), L.fptr(dgamma), L.fptr(dbeta), L.fptr(dx), L.stream_of(x))
+        return dx, dgamma, dbeta, None, None, None
+
+
+def bn_act_rows(x, bn, relu):
+    """[relu](bn(x)) for a row-major (rows, C) fp32 device tensor and an nn.BatchNorm1d in TRAIN mode (batch statistics, running
+    statistics updated), forward + backward on the row-major kernels; None if the shapes do not qualify (C % 4, C > 1024, eval)."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and bn.training and x.shape[1] % 4 == 0 and x.shape[1] <= 1024
+            and x.shape[0] > 0):
+        return None
+    x = x.contiguous()
+    rows, c = x.shape
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    ws = torch.empty((max(L.raw("mgar_bn_cl_workspace_floats", 1, rows, c, 0), 1),), dtype=torch.float32, device=x.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    L.call("mgar_bn_cl_train_stats", L.fptr(x), 1, rows, c, 0, float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1),
+           L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None, L.fptr(bn.running_var) if track else None,
+           L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None, L.stream_of(x))
+    gamma, beta = _affine(bn, c, x.device)
+    return _BnActRows.apply(x, gamma, beta, mean, invstd, relu)
+
+
 SMALL_CHANNEL_MAX = 16384   # csrc/bn_act.hip, bn_small_fused_kernel: elements per channel one workgroup keeps in registers
 
 

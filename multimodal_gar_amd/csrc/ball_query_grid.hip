@@ -229,28 +229,47 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int B, int
         const int x0 = max(pg_cell(qx - rr, g.lo[0], g.inv_h), 0), x1 = min(pg_cell(qx + rr, g.lo[0], g.inv_h), g.dim[0] - 1);
         const int y0 = max(pg_cell(qy - rr, g.lo[1], g.inv_h), 0), y1 = min(pg_cell(qy + rr, g.lo[1], g.inv_h), g.dim[1] - 1);
         const int z0 = max(pg_cell(qz - rr, g.lo[2], g.inv_h), 0), z1 = min(pg_cell(qz + rr, g.lo[2], g.inv_h), g.dim[2] - 1);
-        if (x0 <= x1)
-            for (int cz = z0; cz <= z1; ++cz)
-                for (int cy = y0; cy <= y1; ++cy) {
-                    const int base = (cz * g.dim[1] + cy) * g.dim[0];
-                    const int e = start[base + x1 + 1];
-                    for (int p = start[base + x0]; p < e; ++p) {
-                        const float4 v = pts[p];
-                        const float d2 = d2_of(qx - v.x, qy - v.y, qz - v.z);
-                        if (d2 < radius2) {
-                            int nv = __float_as_int(v.w);
-                            ++cnt;
-                            if (nv < list[NS - 1]) {   // once the list is full of small indices most hits stop here
+        auto hit = [&](const float4 v) {
+            const float d2 = d2_of(qx - v.x, qy - v.y, qz - v.z);
+            if (d2 < radius2) {
+                int nv = __float_as_int(v.w);
+                ++cnt;
+                if (nv < list[NS - 1]) {   // once the list is full of small indices most hits stop here
 #pragma unroll
-                                for (int s = 0; s < NS; ++s) {   // sorted insertion: list keeps the NS smallest indices, ascending
-                                    const int a = list[s];
-                                    list[s] = min(a, nv);
-                                    nv = max(a, nv);
-                                }
-                            }
-                        }
+                    for (int s = 0; s < NS; ++s) {   // sorted insertion: list keeps the NS smallest indices, ascending
+                        const int a = list[s];
+                        list[s] = min(a, nv);
+                        nv = max(a, nv);
                     }
                 }
+            }
+        };
+        // the (cz, cy) rows of the cell range, flattened; every row is ONE contiguous run [start(x0), start(x1 + 1)) of the
+        // sorted points.  The next row's two cell_start loads are issued before the current run is walked, and a run is walked
+        // four points at a time (independent 16-byte loads in flight), so a lane is not a chain of dependent cache misses.
+        const int ny = y1 - y0 + 1, rows_n = (x0 <= x1 && y0 <= y1 && z0 <= z1) ? ny * (z1 - z0 + 1) : 0;
+        const float4 far = make_float4(__builtin_inff(), 0.f, 0.f, 0.f);   // d2 = inf: never a hit
+        int ps = 0, pe = 0;
+        if (rows_n > 0) {
+            const int base = (z0 * g.dim[1] + y0) * g.dim[0];
+            ps = start[base + x0]; pe = start[base + x1 + 1];
+        }
+        for (int t = 0; t < rows_n; ++t) {
+            int ns_ = 0, ne_ = 0;
+            if (t + 1 < rows_n) {
+                const int tz = (t + 1) / ny, ty = (t + 1) - tz * ny;
+                const int base = ((z0 + tz) * g.dim[1] + (y0 + ty)) * g.dim[0];
+                ns_ = start[base + x0]; ne_ = start[base + x1 + 1];
+            }
+            for (int p = ps; p < pe; p += 4) {
+                const float4 v0 = pts[p];
+                const float4 v1 = p + 1 < pe ? pts[p + 1] : far;
+                const float4 v2 = p + 2 < pe ? pts[p + 2] : far;
+                const float4 v3 = p + 3 < pe ? pts[p + 3] : far;
+                hit(v0); hit(v1); hit(v2); hit(v3);
+            }
+            ps = ns_; pe = ne_;
+        }
     }
     const int c = min(cnt, nsample);
 #pragma unroll

@@ -154,6 +154,89 @@ static inline int cl_chunk_rows(int S, int R) {
     return (int)want;
 }
 
+// ---- backward for ROW-MAJOR activations (round 3: the sparse trunk's (N_active, C) features) ------------------------------
+// BatchNorm1d (train statistics) [+ ReLU] over the rows of x (rows, C): the same two passes as csrc/bn_act.hip, indexed like the
+// forward kernels above.  partial[(c * nchunk + k) * 2 + {0, 1}] = sum dz, sum dz * xhat over chunk k (bn_bwd_finalize_kernel's
+// format); dz = dy * [relu active], the mask being the forward's expression bit for bit.
+template <bool RELU>
+__global__ __launch_bounds__(CL_THREADS) void bn_rows_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x, int R, int C,
+                                                                         int chunk, const float *__restrict__ mean,
+                                                                         const float *__restrict__ invstd, const float *__restrict__ gamma,
+                                                                         const float *__restrict__ beta, float *__restrict__ partial) {
+    __shared__ float4 red_s[CL_THREADS], red_q[CL_THREADS];
+    const int ng = C >> 2, rpar = CL_THREADS / ng;
+    const int j = threadIdx.x % ng, rr = threadIdx.x / ng;
+    const int k = blockIdx.x, nchunk = gridDim.x;
+    const int r0 = k * chunk, r1 = min(r0 + chunk, R);
+    float4 sum = make_float4(0.f, 0.f, 0.f, 0.f), sq = sum;
+    if (rr < rpar) {
+        const int c = 4 * j;
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+        const float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b = beta ? *reinterpret_cast<const float4 *>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = r0 + rr; r < r1; r += rpar) {
+            const float4 xv = *reinterpret_cast<const float4 *>(x + (size_t)r * C + c);
+            float4 d = *reinterpret_cast<const float4 *>(dy + (size_t)r * C + c);
+            if (RELU) {
+                if (!((xv.x - mu.x) * (is.x * g.x) + b.x > 0.f)) d.x = 0.f;
+                if (!((xv.y - mu.y) * (is.y * g.y) + b.y > 0.f)) d.y = 0.f;
+                if (!((xv.z - mu.z) * (is.z * g.z) + b.z > 0.f)) d.z = 0.f;
+                if (!((xv.w - mu.w) * (is.w * g.w) + b.w > 0.f)) d.w = 0.f;
+            }
+            sum.x += d.x; sum.y += d.y; sum.z += d.z; sum.w += d.w;
+            sq.x += d.x * ((xv.x - mu.x) * is.x); sq.y += d.y * ((xv.y - mu.y) * is.y);
+            sq.z += d.z * ((xv.z - mu.z) * is.z); sq.w += d.w * ((xv.w - mu.w) * is.w);
+        }
+    }
+    red_s[threadIdx.x] = sum;
+    red_q[threadIdx.x] = sq;
+    __syncthreads();
+    if (threadIdx.x < ng) {                                  // rr == 0 threads: add the row lanes in order
+        for (int q = 1; q < rpar; ++q) {
+            const float4 a = red_s[q * ng + j], b = red_q[q * ng + j];
+            sum.x += a.x; sum.y += a.y; sum.z += a.z; sum.w += a.w;
+            sq.x += b.x; sq.y += b.y; sq.z += b.z; sq.w += b.w;
+        }
+        const float sv[4] = {sum.x, sum.y, sum.z, sum.w}, qv[4] = {sq.x, sq.y, sq.z, sq.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *dst = partial + ((size_t)(4 * j + i) * nchunk + k) * 2;
+            dst[0] = sv[i];
+            dst[1] = qv[i];
+        }
+    }
+}
+
+// dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); 8 B read + 4 B written per element
+template <bool RELU>
+__global__ __launch_bounds__(CL_THREADS) void bn_rows_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, long long rows,
+                                                                       int C, const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                       const float *__restrict__ coef, float *__restrict__ dx) {
+    const int ng = C >> 2;
+    const long long total = rows * ng;
+    for (long long e = (long long)blockIdx.x * CL_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * CL_THREADS) {
+        const long long row = e / ng;
+        const int c = (int)(e - row * ng) * 4;
+        const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+        const float4 g = gamma ? *reinterpret_cast<const float4 *>(gamma + c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b = beta ? *reinterpret_cast<const float4 *>(beta + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 xv = *reinterpret_cast<const float4 *>(x + row * C + c);
+        float4 d = *reinterpret_cast<const float4 *>(dy + row * C + c);
+        float4 r;
+        auto one = [&](float xs, float ds, float m, float i, float gg, float bb, float m0, float m1) {
+            const float k = i * gg;
+            if (RELU && !((xs - m) * k + bb > 0.f)) ds = 0.f;
+            return k * (ds - m0 - (xs - m) * i * m1);
+        };
+        r.x = one(xv.x, d.x, mu.x, is.x, g.x, b.x, coef[2 * c + 0], coef[2 * c + 1]);
+        r.y = one(xv.y, d.y, mu.y, is.y, g.y, b.y, coef[2 * c + 2], coef[2 * c + 3]);
+        r.z = one(xv.z, d.z, mu.z, is.z, g.z, b.z, coef[2 * c + 4], coef[2 * c + 5]);
+        r.w = one(xv.w, d.w, mu.w, is.w, g.w, b.w, coef[2 * c + 6], coef[2 * c + 7]);
+        *reinterpret_cast<float4 *>(dx + row * C + c) = r;
+    }
+}
+
 }  // namespace mgar
 
 #define CL_API extern "C" __attribute__((visibility("default")))
@@ -286,4 +369,36 @@ CL_API int mgar_maxpool3d_same_fwd_cl(const float *x, int N, int T, int H, int W
 CL_API int mgar_maxpool3d_same_fwd_cl_bf16(const void *x, int N, int T, int H, int W, int C, int kt, int kh, int kw, int st, int sh,
                                            int sw, void *y, void *stream) {
     return maxpool3d_cl_impl<bf16_t>((const bf16_t *)x, N, T, H, W, C, kt, kh, kw, st, sh, sw, (bf16_t *)y, stream);
+}
+
+// BatchNorm1d(train) [+ ReLU] backward over ROW-MAJOR x, dy (rows, C) fp32 (the sparse trunk's features): dx (rows, C), dgamma,
+// dbeta (C).  workspace: mgar_bn_rows_bwd_workspace_floats(rows, C) floats.  C % 4 == 0, C <= 1024.
+CL_API long long mgar_bn_rows_bwd_workspace_floats(int rows, int C) {
+    if (!cl_shape_ok(1, rows, C)) return -1;
+    const int chunk = cl_chunk_rows(1, rows), nchunk = (rows + chunk - 1) / chunk;
+    return 2ll * C * (nchunk > 0 ? nchunk : 1) + 2ll * C;
+}
+CL_API int mgar_bn_rows_bwd(const float *dy, const float *x, int rows, int C, const float *mean, const float *invstd, const float *gamma,
+                            const float *beta, int relu, float *workspace, float *dgamma, float *dbeta, float *dx, void *stream) {
+    MGAR_REQUIRE(cl_shape_ok(1, rows, C), "bn_rows_bwd: needs C % 4 == 0, C <= 1024");
+    if ((long long)rows * C == 0) return MGAR_OK;
+    MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx, "bn_rows_bwd: null pointer");
+    const int chunk = cl_chunk_rows(1, rows), nchunk = (rows + chunk - 1) / chunk;
+    hipStream_t st = (hipStream_t)stream;
+    float *coef = workspace + (size_t)2 * C * nchunk;
+    {
+        KtScope kt(KT_BN_BWD_REDUCE, st, 8.0 * (double)rows * C);
+        if (relu) hipLaunchKernelGGL(bn_rows_bwd_partial_kernel<true>, dim3(nchunk), dim3(CL_THREADS), 0, st, dy, x, rows, C, chunk, mean, invstd, gamma, beta, workspace);
+        else hipLaunchKernelGGL(bn_rows_bwd_partial_kernel<false>, dim3(nchunk), dim3(CL_THREADS), 0, st, dy, x, rows, C, chunk, mean, invstd, gamma, beta, workspace);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, st, workspace, nchunk, C, (double)rows, dgamma, dbeta, coef);
+    const long long total = (long long)rows * (C / 4);
+    long long blocks = (total + CL_THREADS - 1) / CL_THREADS;
+    if (blocks > 16384) blocks = 16384;
+    {
+        KtScope kt(KT_BN_BWD_APPLY, st, 12.0 * (double)rows * C);
+        if (relu) hipLaunchKernelGGL(bn_rows_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(CL_THREADS), 0, st, dy, x, (long long)rows, C, mean, invstd, gamma, beta, coef, dx);
+        else hipLaunchKernelGGL(bn_rows_bwd_apply_kernel<false>, dim3((unsigned)blocks), dim3(CL_THREADS), 0, st, dy, x, (long long)rows, C, mean, invstd, gamma, beta, coef, dx);
+    }
+    return check_launch("bn_rows_bwd: launch failed");
 }

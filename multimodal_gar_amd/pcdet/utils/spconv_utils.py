@@ -115,13 +115,28 @@ class SparseSequential(SparseModule):
         return len(self._modules)
 
     def forward(self, x):
-        for module in self._modules.values():
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            module = mods[i]
             if isinstance(module, SparseModule):
                 x = module(x)
             elif isinstance(x, SparseConvTensor):
-                x = x.replace_feature(module(x.features))
+                feats = x.features
+                if isinstance(module, nn.BatchNorm1d) and feats.is_cuda:
+                    # BatchNorm1d [+ ReLU] on the row-major (N_active, C) features in the library's row-major kernels (one
+                    # statistics pass, one apply pass; backward likewise) instead of torch's native batch norm + threshold
+                    from ... import bn_ops
+                    relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    y = bn_ops.bn_act_rows(feats, module, relu)
+                    if y is not None:
+                        x = x.replace_feature(y)
+                        i += 2 if relu else 1
+                        continue
+                x = x.replace_feature(module(feats))
             else:
                 x = module(x)
+            i += 1
         return x
 
 
