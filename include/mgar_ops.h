@@ -596,6 +596,15 @@ int mgar_spconv_dw_chunks(int No);
  * partial (n_items, Cin, Cout) scratch; dw (K, Cin, Cout) fully written, summed in item order (reproducible).
  * C_in, C_out powers of two <= 128 (MGAR_EUNSUPPORTED otherwise: mgar_spconv_dw). */
 int mgar_spconv_pair_chunk(void);
+/* The pair lists themselves, built on the device from the neighbour table nbr (No, K) (round 3; replaces six torch passes):
+ * mgar_spconv_pairs_count fills blk (K, mgar_spconv_pairs_blocks(No)) int32 (per-row-block counts, scanned per offset) and total (K)
+ * int32; the caller reads total (one host synchronisation per rulebook), forms offset_start (K) int64 = exclusive sums, allocates
+ * pair_i / pair_o (sum total) and calls mgar_spconv_pairs_fill: offset k's pairs land at [offset_start[k], +total[k]), ascending
+ * output row (stable, deterministic). */
+int mgar_spconv_pairs_blocks(int No);
+int mgar_spconv_pairs_count(int No, int K, const int *nbr, int *blk, int *total, void *stream);
+int mgar_spconv_pairs_fill(int No, int K, const int *nbr, const int *blk, const long long *offset_start, int *pair_i, int *pair_o,
+                           void *stream);
 /* Forward / data gradient over the same pair lists: for k = 0 .. K-1 in order, dst[pair_dst[p], :] += src[pair_src[p], :] . w[k]
  * over the pairs of offset k (one launch per offset: under one offset a destination row occurs once, so the update needs no
  * atomics and the order of the sum over k is fixed).  dst (rows, Cd) ZERO-FILLED by the caller; w (K, Cs, Cd) row-major;

@@ -501,6 +501,89 @@ static bool sp_geom_ok(const int *g) {
     return true;
 }
 
+// ---- pair lists from the neighbour table, on the device (round 3) -------------------------------------------------------------
+// nbr (No, K) -> for every offset k the (input row, output row) pairs with a neighbour, ascending output row, offsets one after
+// another: pair_i / pair_o (P).  Three launches instead of the six torch passes (mask, transpose, sum, nonzero, two index
+// gathers: ~10 ms per rulebook at 4 M sites):
+//   sp_pairs_count_kernel  a workgroup owns SP_PB consecutive rows: per offset, how many of them have a neighbour -> blk (K, nblk)
+//   sp_pairs_scan_kernel   one workgroup per offset: exclusive scan over the row blocks (in place) + the offset's total
+//   sp_pairs_fill_kernel   the same workgroups rank their rows per offset (ballot prefix inside a wave, the waves in order) and write
+//                          the pairs at  offset_start[k] + blk[k][b] + rank  -- stable: ascending output row, deterministic.
+constexpr int SP_PB = 1024;   // rows per workgroup (256 lanes x 4 row groups)
+
+__global__ __launch_bounds__(256) void sp_pairs_count_kernel(int No, int K, const int *__restrict__ nbr, int *__restrict__ blk) {
+    extern __shared__ int lcnt[];   // K counters
+    const int b = blockIdx.x, nblk = gridDim.x;
+    for (int k = threadIdx.x; k < K; k += 256) lcnt[k] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int g = 0; g < SP_PB / 256; ++g) {
+        const int row = b * SP_PB + g * 256 + threadIdx.x;
+        const int *r = nbr + (size_t)row * K;
+        for (int k = 0; k < K; ++k) {
+            const bool has = row < No && r[k] >= 0;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+            if (lane == 0 && m) atomicAdd(&lcnt[k], __builtin_popcountll(m));
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) blk[(size_t)k * nblk + b] = lcnt[k];
+}
+
+__global__ __launch_bounds__(1024) void sp_pairs_scan_kernel(int nblk, int *__restrict__ blk, int *__restrict__ total) {
+    __shared__ int part[1024];
+    const int k = blockIdx.x, t = threadIdx.x;
+    int *row = blk + (size_t)k * nblk;
+    const int per = (nblk + 1023) / 1024;
+    const int b0 = t * per, b1 = min(b0 + per, nblk);
+    int s = 0;
+    for (int b = b0; b < b1; ++b) s += row[b];
+    part[t] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int add = t >= off ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    int run = part[t] - s;
+    for (int b = b0; b < b1; ++b) { const int c = row[b]; row[b] = run; run += c; }
+    if (t == 1023) total[k] = part[1023];
+}
+
+__global__ __launch_bounds__(256) void sp_pairs_fill_kernel(int No, int K, const int *__restrict__ nbr, const int *__restrict__ blk,
+                                                            const long long *__restrict__ offset_start, int *__restrict__ pair_i,
+                                                            int *__restrict__ pair_o) {
+    extern __shared__ int lrun[];   // K running ranks inside this workgroup
+    __shared__ int wcnt[4];
+    const int b = blockIdx.x, nblk = gridDim.x;
+    for (int k = threadIdx.x; k < K; k += 256) lrun[k] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int g = 0; g < SP_PB / 256; ++g) {
+        const int row = b * SP_PB + g * 256 + threadIdx.x;
+        const int *r = nbr + (size_t)row * K;
+        for (int k = 0; k < K; ++k) {
+            const int v = row < No ? r[k] : -1;
+            const bool has = v >= 0;
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+            if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
+            __syncthreads();
+            int before = lrun[k];
+            for (int w = 0; w < wave; ++w) before += wcnt[w];
+            const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];   // read before the barrier below: the next offset overwrites wcnt
+            if (has) {
+                const long long pos = offset_start[k] + blk[(size_t)k * nblk + b] + before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                pair_i[pos] = v;
+                pair_o[pos] = row;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) lrun[k] += all;
+        }
+    }
+}
+
 }  // namespace mgar
 
 using namespace mgar;
@@ -700,4 +783,33 @@ SP_API int mgar_spconv_pairs_gemm(int K, int Cs, int Cd, const float *src, const
         else hipLaunchKernelGGL(spconv_pairs_gemm_kernel<32>, dim3(n), dim3(256), lds, st, Cs, Cd, src, pair_src, pair_dst, it, wk, dst);
     }
     return check_launch("spconv_pairs_gemm: launch failed");
+}
+
+// Pair lists of a rulebook on the device.  Step 1: mgar_spconv_pairs_count fills blk (K, nblk) int32 with the per-row-block counts,
+// scanned per offset, and total (K) int32; nblk = mgar_spconv_pairs_blocks(No).  The caller reads `total` (the one host
+// synchronisation of a rulebook), forms offset_start (K) int64 = exclusive sums of total, allocates pair_i / pair_o (sum of total) and
+// calls step 2, mgar_spconv_pairs_fill: pairs of offset k at [offset_start[k], offset_start[k] + total[k]), ascending output row.
+SP_API int mgar_spconv_pairs_blocks(int No) { return No < 0 ? MGAR_EINVAL : (No + SP_PB - 1) / SP_PB; }
+SP_API int mgar_spconv_pairs_count(int No, int K, const int *nbr, int *blk, int *total, void *stream) {
+    MGAR_REQUIRE(No >= 0 && K >= 1 && K <= 4096, "spconv_pairs_count: bad sizes");
+    MGAR_REQUIRE(total, "spconv_pairs_count: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (No == 0) { (void)hipMemsetAsync(total, 0, sizeof(int) * K, st); return MGAR_OK; }
+    MGAR_REQUIRE(nbr && blk, "spconv_pairs_count: null pointer");
+    const int nblk = (No + SP_PB - 1) / SP_PB;
+    KtScope kt(KT_SPCONV_INDEX, st, 4.0 * (double)No * K);
+    hipLaunchKernelGGL(sp_pairs_count_kernel, dim3(nblk), dim3(256), K * sizeof(int), st, No, K, nbr, blk);
+    hipLaunchKernelGGL(sp_pairs_scan_kernel, dim3(K), dim3(1024), 0, st, nblk, blk, total);
+    return check_launch("spconv_pairs_count: launch failed");
+}
+SP_API int mgar_spconv_pairs_fill(int No, int K, const int *nbr, const int *blk, const long long *offset_start, int *pair_i, int *pair_o,
+                                  void *stream) {
+    MGAR_REQUIRE(No >= 0 && K >= 1 && K <= 4096, "spconv_pairs_fill: bad sizes");
+    if (No == 0) return MGAR_OK;
+    MGAR_REQUIRE(nbr && blk && offset_start && pair_i && pair_o, "spconv_pairs_fill: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = (No + SP_PB - 1) / SP_PB;
+    KtScope kt(KT_SPCONV_INDEX, st, 4.0 * (double)No * K + 8.0 * (double)No * K / 3.0);
+    hipLaunchKernelGGL(sp_pairs_fill_kernel, dim3(nblk), dim3(256), K * sizeof(int), st, No, K, nbr, blk, offset_start, pair_i, pair_o);
+    return check_launch("spconv_pairs_fill: launch failed");
 }

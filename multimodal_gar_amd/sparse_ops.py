@@ -105,13 +105,22 @@ class Rulebook:
         mgar_spconv_pair_chunk() pairs, item_start (K + 1) int32 and the item count for the weight gradient; a finer cut of the
         same pairs and its item_start as a host array for the per-offset launches of the forward / data gradient."""
         if self._pairs is None:
-            mask_t = (self.nbr >= 0).t().contiguous()                            # (K, No)
-            counts = mask_t.sum(1).tolist()                                      # one host synchronisation per rulebook
-            ko = torch.nonzero(mask_t)                                           # rows [k, o], k-major, o ascending
-            pair_o = ko[:, 1].int().contiguous()
-            pair_i = self.nbr.t()[mask_t].contiguous()
-            chunk = L.raw("mgar_spconv_pair_chunk")
             dev = self.nbr.device
+            n_out = self.nbr.shape[0]
+            # csrc/sparse_conv.hip, sp_pairs_*: count per (offset, row block) -> scan -> stable fill; three launches
+            nblk = max(L.raw("mgar_spconv_pairs_blocks", n_out), 1)
+            blk = torch.empty((self.K, nblk), dtype=torch.int32, device=dev)
+            total = torch.empty((self.K,), dtype=torch.int32, device=dev)
+            st = L.stream_of(self.nbr)
+            L.call("mgar_spconv_pairs_count", n_out, self.K, L.iptr(self.nbr), L.iptr(blk), L.iptr(total), st)
+            counts = total.tolist()                                              # one host synchronisation per rulebook
+            self._pair_count = sum(counts)
+            starts = torch.tensor([0] + counts[:-1], dtype=torch.int64).cumsum(0).to(dev)
+            pair_i = torch.empty((max(self._pair_count, 1),), dtype=torch.int32, device=dev)
+            pair_o = torch.empty_like(pair_i)
+            L.call("mgar_spconv_pairs_fill", n_out, self.K, L.iptr(self.nbr), L.iptr(blk), L.dev_ptr(starts, torch.int64), L.iptr(pair_i),
+                   L.iptr(pair_o), st)
+            chunk = L.raw("mgar_spconv_pair_chunk")
 
             def cut(chunk_of):
                 import numpy as np

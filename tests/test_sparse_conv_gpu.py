@@ -199,3 +199,31 @@ def test_pair_list_kernels_equal_the_table_driven_ones(subm, kernel, stride, pad
         assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-6), what
     for a, b in zip(res[0][:3], res[2][:3]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("subm,kernel,stride,padding,n_scale", [(True, 3, 1, 1, 1), (False, 3, 2, 1, 1), (False, (3, 1, 1), (2, 1, 1), 0, 1),
+                                                                 (True, 3, 1, 1, 6)])
+def test_device_pair_list_builder_equals_the_torch_definition(subm, kernel, stride, padding, n_scale):
+    """csrc/sparse_conv.hip sp_pairs_{count,scan,fill}: the pair lists of a rulebook (per offset: the (input row, output row) of every
+    output site with a neighbour, ascending output row) against their definition in torch (mask -> nonzero -> gather); more
+    than one 1 024-row block, ragged tail, empty offsets."""
+    from multimodal_gar_amd import sparse_ops
+    shape, batch = [12, 40 * n_scale, 44], 3
+    idx = sparse_sites(5, batch, tuple(shape), 0.10).cuda()
+    rb = sparse_ops.Rulebook(idx, shape, batch, kernel, stride, padding, subm)
+    pair_i, pair_o, items_dw, start_dw, n_dw, items_fw, start_fw = rb.pairs()
+    mask_t = (rb.nbr >= 0).t().contiguous()
+    counts = mask_t.sum(1)
+    ko = torch.nonzero(mask_t)
+    want_o = ko[:, 1].int()
+    want_i = rb.nbr.t()[mask_t]
+    p = int(counts.sum())
+    assert p == rb.pair_count() and p > 1000 and rb.nbr.shape[0] > (1024 if n_scale == 1 else 4096)
+    assert torch.equal(pair_o[:p], want_o) and torch.equal(pair_i[:p], want_i)
+    # the items cover every pair exactly once, offset by offset
+    it = items_dw[:n_dw].cpu().numpy()
+    covered = sum(int(e - b) for _, b, e, _ in it)
+    assert covered == p
+    offs = np.concatenate([[0], np.cumsum(counts.cpu().numpy())])
+    for k, b, e, _ in it:
+        assert offs[k] <= b < e <= offs[k + 1]
