@@ -32,5 +32,8 @@ def wanted(points_per_cloud, nsamples):
 
 
 def cell_for(radii):
-    """Cell edge for a set of query radii: the smallest radius (the library enlarges it until the grid fits its cell budget)."""
-    return max(min(float(r) for r in radii), 1e-3)
+    """Cell edge for a set of query radii: 3/4 of the largest, but not below the smallest (measured at the RoI lift's radii
+    0.4 / 0.8 / 1.6: cell 0.4 -> 2.30 ms, 0.8 -> 1.80, 1.2 -> 1.67 for the three queries of config c3; the library enlarges
+    the cell until the grid fits its cell budget, which is what decides for the trunk's small radii)."""
+    rs = [float(r) for r in radii]
+    return max(min(rs), 0.75 * max(rs), 1e-3)
