@@ -125,6 +125,13 @@ int mgar_ball_query_grid_batch(int b, int n, int m, float radius, int nsample, c
                                void *stream);
 int mgar_ball_query_grid_stack(int B, int M, long long n_total, float radius, int nsample, const float *new_xyz,
                                const int *new_xyz_batch_cnt, const void *grid, int *idx, void *stream);
+/* three_nn of mgar_three_nn_batch / _stack (same dist2 / idx, bit for bit -- the reference's strict-'<' cascade keeps the three
+ * smallest (d2, index) pairs) through a grid built over the KNOWN points with mgar_point_grid_build (cell <= 0: the library sizes
+ * the cells at about -cell, default 4, points each): shells of cells around the query until the third neighbour is closer than
+ * anything unvisited.  m_total = rows of `known`. */
+int mgar_three_nn_grid_batch(int b, int n, int m, const float *unknown, const void *grid, float *dist2, int *idx, void *stream);
+int mgar_three_nn_grid_stack(int B, int N, long long m_total, const float *unknown, const int *unknown_batch_cnt, const void *grid,
+                             float *dist2, int *idx, void *stream);
 
 /* three_nn_wrapper   pointnet2_api.cpp:21;  kernel interpolate_gpu.cu:16-59
  * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3). */

@@ -37,6 +37,8 @@ _PROTOS = {
     "mgar_point_grid_build": [_I, _I, ctypes.c_longlong, _P, _P, _F, _P, _P],
     "mgar_ball_query_grid_batch": [_I, _I, _I, _F, _I, _P, _P, _P, _P],
     "mgar_ball_query_grid_stack": [_I, _I, ctypes.c_longlong, _F, _I, _P, _P, _P, _P, _P],
+    "mgar_three_nn_grid_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_three_nn_grid_stack": [_I, _I, ctypes.c_longlong, _P, _P, _P, _P, _P, _P],
     "mgar_fps_batch_buckets": [_I, _I, _I, _P, _P, _P, _P, _P, _P],
     "mgar_fps_batch_buckets_workspace_floats": [_I, _I],
     "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],

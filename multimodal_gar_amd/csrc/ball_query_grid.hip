@@ -93,6 +93,15 @@ __global__ __launch_bounds__(1024) void pg_geom_kernel(int n_batch, const float 
     // cell edge: the caller's, enlarged until the grid has at most PG_MAX_CELLS cells (dim = floor(ext / h) + 1 per axis:
     // every point's cell index is then inside [0, dim) without clamping)
     float h = cell;
+    if (!(h > 0.f)) {
+        // automatic: ~|cell| (default 4) points per cell of the occupied box; flat or degenerate boxes fall back on their largest extent
+        const float target = cell < 0.f ? -cell : 4.f;
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const float emax = fmaxf(fmaxf(ex, ey), fmaxf(ez, 1e-6f));
+        const float vol = fmaxf(ex, 1e-3f * emax) * fmaxf(ey, 1e-3f * emax) * fmaxf(ez, 1e-3f * emax);
+        h = cbrtf(vol * target / (float)(n > 0 ? n : 1));
+        h = fmaxf(h, 1e-6f * emax);
+    }
     int d[3];
     for (int it = 0; it < 200; ++it) {
         const float ih = 1.f / h;
@@ -291,6 +300,106 @@ __global__ __launch_bounds__(BQG_THREADS) void ball_query_grid_kernel(int B, int
     }
 }
 
+// ---- three nearest neighbours through the grid --------------------------------------------------------------------------------
+// three_nn of csrc/interpolate.hip (reference pointnet2_batch/src/interpolate_gpu.cu:16-59, stack :16-81), bit for bit: the
+// reference's strict-'<' cascade in index order keeps, among equal distances, the EARLIEST index, i.e. its result is the three
+// smallest (d2, k) pairs in lexicographic order -- a property of the candidate SET, so the cells may be visited in any order as
+// long as every point that could enter the top three is seen.  Shells of cells of growing Chebyshev radius s around the query's
+// cell are walked until the third-best distance is strictly smaller than the distance from the query to the boundary of the cube
+// of shells 0..s (every unvisited point lies outside that cube); missing neighbours keep (inf, 0) as the reference (1e40 -> inf).
+__device__ __forceinline__ void tn_consider(float d, int k, float &b1, float &b2, float &b3, int &i1, int &i2, int &i3) {
+    if (d < b3 || (d == b3 && k < i3)) {
+        if (d < b2 || (d == b2 && k < i2)) {
+            b3 = b2; i3 = i2;
+            if (d < b1 || (d == b1 && k < i1)) { b2 = b1; i2 = i1; b1 = d; i1 = k; }
+            else { b2 = d; i2 = k; }
+        } else { b3 = d; i3 = k; }
+    }
+}
+
+template <bool STACK>
+__global__ __launch_bounds__(BQG_THREADS) void three_nn_grid_kernel(int B, int n_batch, const float *__restrict__ unknown,
+                                                                    const int *__restrict__ unknown_batch_cnt,
+                                                                    const PgGeom *__restrict__ geom, const int *__restrict__ cell_start,
+                                                                    const float4 *__restrict__ sorted, float *__restrict__ dist2,
+                                                                    int *__restrict__ idx) {
+    int u0, u_end, bs;
+    if (STACK) {
+        int g = blockIdx.x, us = 0;
+        bool found = false;
+        for (bs = 0; bs < B; ++bs) {
+            const int ni = unknown_batch_cnt[bs];
+            const int nb = (ni + BQG_THREADS - 1) / BQG_THREADS;
+            if (g < nb) { found = true; break; }
+            g -= nb;
+            us += ni;
+        }
+        if (!found) return;
+        u0 = us + g * BQG_THREADS;
+        u_end = us + unknown_batch_cnt[bs];
+    } else {
+        bs = blockIdx.y;
+        u0 = bs * n_batch + blockIdx.x * BQG_THREADS;
+        u_end = (bs + 1) * n_batch;
+    }
+    const int u = u0 + threadIdx.x;
+    if (u >= u_end) return;
+    const PgGeom g = geom[bs];
+    const int *__restrict__ start = cell_start + (size_t)bs * (PG_MAX_CELLS + 1);
+    const float4 *__restrict__ pts = sorted + g.pstart;
+    const float ux = unknown[(size_t)u * 3 + 0], uy = unknown[(size_t)u * 3 + 1], uz = unknown[(size_t)u * 3 + 2];
+    const float inf = __builtin_inff();
+    float b1 = inf, b2 = inf, b3 = inf;
+    int i1 = 0, i2 = 0, i3 = 0;
+    if (g.n > 0) {
+        const int dx = g.dim[0], dy = g.dim[1], dz = g.dim[2];
+        const int cx = min(max(pg_cell(ux, g.lo[0], g.inv_h), 0), dx - 1), cy = min(max(pg_cell(uy, g.lo[1], g.inv_h), 0), dy - 1);
+        const int cz = min(max(pg_cell(uz, g.lo[2], g.inv_h), 0), dz - 1);
+        auto run = [&](int base, int xa, int xb) {   // cells base + xa .. base + xb: one contiguous run of the sorted points
+            const int e = start[base + xb + 1];
+            for (int p = start[base + xa]; p < e; ++p) {
+                const float4 v = pts[p];
+                tn_consider(d2_of(ux - v.x, uy - v.y, uz - v.z), __float_as_int(v.w), b1, b2, b3, i1, i2, i3);
+            }
+        };
+        const int smax = max(max(max(cx, dx - 1 - cx), max(cy, dy - 1 - cy)), max(cz, dz - 1 - cz));
+        for (int s = 0; s <= smax; ++s) {
+            const int x0 = max(cx - s, 0), x1 = min(cx + s, dx - 1), y0 = max(cy - s, 0), y1 = min(cy + s, dy - 1);
+            const int z0 = max(cz - s, 0), z1 = min(cz + s, dz - 1);
+            for (int z = z0; z <= z1; ++z) {
+                const bool zface = (z == cz - s) || (z == cz + s);
+                for (int y = y0; y <= y1; ++y) {
+                    const int base = (z * dy + y) * dx;
+                    if (zface || y == cy - s || y == cy + s) {
+                        run(base, x0, x1);                                   // a whole row of the shell's z / y faces
+                    } else {
+                        if (cx - s >= 0) run(base, cx - s, cx - s);          // the two x end cells
+                        if (cx + s <= dx - 1) run(base, cx + s, cx + s);
+                    }
+                }
+            }
+            // every unvisited point lies outside the cube of cells [c - s, c + s]: along at least one axis it is beyond the cube's
+            // face, unless the cube already reaches the end of the grid on that side
+            float bound = inf;
+            const float q[3] = {ux, uy, uz};
+            const int c[3] = {cx, cy, cz}, dim[3] = {dx, dy, dz};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] - s > 0) bound = fminf(bound, q[a] - (g.lo[a] + (float)(c[a] - s) * g.h));
+                if (c[a] + s < dim[a] - 1) bound = fminf(bound, (g.lo[a] + (float)(c[a] + s + 1) * g.h) - q[a]);
+            }
+            if (bound == inf) break;                                         // the cube covers the grid
+            // the cell map floor((v - lo) * inv_h) and these face coordinates lo + c * h round differently: by at most ~2e-7 * dim
+            // cells (relative rounding of a value <= dim), so a margin of 1e-6 * dim cells is safe
+            bound -= g.h * (1e-6f * (float)max(dx, max(dy, dz)) + 1e-5f);
+            if (bound > 0.f && b3 < bound * bound) break;
+        }
+    }
+    const int off = STACK ? g.pstart : 0;   // the stack op returns global rows (interpolate_gpu.cu:72-74)
+    dist2[(size_t)u * 3 + 0] = b1; dist2[(size_t)u * 3 + 1] = b2; dist2[(size_t)u * 3 + 2] = b3;
+    idx[(size_t)u * 3 + 0] = i1 + off; idx[(size_t)u * 3 + 1] = i2 + off; idx[(size_t)u * 3 + 2] = i3 + off;
+}
+
 }  // namespace mgar
 
 using namespace mgar;
@@ -302,13 +411,14 @@ BQG_API long long mgar_point_grid_workspace_bytes(int B, long long n_total) {
     return (long long)pg_layout(B, n_total).total;
 }
 
-// Bins the points of B clouds into cells of edge `cell` (enlarged per cloud until it has at most 32 768 cells).
+// Bins the points of B clouds into cells of edge `cell` (enlarged per cloud until it has at most 32 768 cells); cell <= 0: chosen
+// per cloud so that a cell of the occupied box holds about -cell (0: four) points.
 // Batch layout: n_batch > 0 points per cloud, xyz_batch_cnt == NULL; stack layout: n_batch == 0, xyz_batch_cnt (B) on the device.
 // n_total = rows of xyz.  workspace: mgar_point_grid_workspace_bytes(B, n_total) bytes, 16-byte aligned; it is what
 // mgar_ball_query_grid_* take, valid for as long as xyz is unchanged.
 BQG_API int mgar_point_grid_build(int B, int n_batch, long long n_total, const float *xyz, const int *xyz_batch_cnt, float cell,
                                   void *workspace, void *stream) {
-    MGAR_REQUIRE(B >= 0 && n_batch >= 0 && n_total >= 0 && cell > 0.f, "point_grid_build: bad sizes");
+    MGAR_REQUIRE(B >= 0 && n_batch >= 0 && n_total >= 0 && cell == cell, "point_grid_build: bad sizes");
     if (B == 0 || n_total == 0) return MGAR_OK;
     MGAR_REQUIRE(xyz && workspace && (n_batch > 0 || xyz_batch_cnt), "point_grid_build: null pointer");
     MGAR_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "point_grid_build: workspace must be 16-byte aligned");
@@ -379,4 +489,33 @@ BQG_API int mgar_ball_query_grid_stack(int B, int M, long long n_total, float ra
     }
     MGAR_REQUIRE(grid, "ball_query_grid_stack: null grid");
     return bqg_launch<true>(B, 0, M, n_total, radius, nsample, new_xyz, new_xyz_batch_cnt, grid, idx, stream);
+}
+
+// three_nn of mgar_three_nn_batch / _stack through a grid built over the KNOWN points (mgar_point_grid_build(known ...); cell <= 0
+// lets the library size the cells).  dist2 (.., 3) squared distances, idx (.., 3) (stack: global rows), as the scan kernels.
+BQG_API int mgar_three_nn_grid_batch(int b, int n, int m, const float *unknown, const void *grid, float *dist2, int *idx, void *stream) {
+    MGAR_REQUIRE(b >= 0 && n >= 0 && m >= 0, "three_nn_grid_batch: negative size");
+    if (b == 0 || n == 0) return MGAR_OK;
+    MGAR_REQUIRE(unknown && dist2 && idx && grid && m > 0, "three_nn_grid_batch: null pointer or no known points (use mgar_three_nn_batch)");
+    hipStream_t st = (hipStream_t)stream;
+    const PgLayout l = pg_layout(b, (long long)b * m);
+    const char *ws = (const char *)grid;
+    KtScope kt(KT_THREE_NN_GRID, st, (double)b * (12.0 * n + 12.0 * m + 24.0 * n));
+    hipLaunchKernelGGL(three_nn_grid_kernel<false>, dim3(ceil_div(n, BQG_THREADS), b), dim3(BQG_THREADS), 0, st, b, n, unknown, (const int *)nullptr,
+                       (const PgGeom *)(ws + l.geom), (const int *)(ws + l.cell_start), (const float4 *)(ws + l.sorted), dist2, idx);
+    return check_launch("three_nn_grid_batch: launch failed");
+}
+BQG_API int mgar_three_nn_grid_stack(int B, int N, long long m_total, const float *unknown, const int *unknown_batch_cnt, const void *grid,
+                                     float *dist2, int *idx, void *stream) {
+    MGAR_REQUIRE(B >= 0 && N >= 0 && m_total >= 0, "three_nn_grid_stack: negative size");
+    if (B == 0 || N == 0) return MGAR_OK;
+    MGAR_REQUIRE(unknown && unknown_batch_cnt && dist2 && idx && grid && m_total > 0,
+                 "three_nn_grid_stack: null pointer or no known points (use mgar_three_nn_stack)");
+    hipStream_t st = (hipStream_t)stream;
+    const PgLayout l = pg_layout(B, m_total);
+    const char *ws = (const char *)grid;
+    KtScope kt(KT_THREE_NN_GRID, st, 12.0 * N + 12.0 * (double)m_total + 24.0 * N);
+    hipLaunchKernelGGL(three_nn_grid_kernel<true>, dim3(ceil_div(N, BQG_THREADS) + B), dim3(BQG_THREADS), 0, st, B, 0, unknown, unknown_batch_cnt,
+                       (const PgGeom *)(ws + l.geom), (const int *)(ws + l.cell_start), (const float4 *)(ws + l.sorted), dist2, idx);
+    return check_launch("three_nn_grid_stack: launch failed");
 }

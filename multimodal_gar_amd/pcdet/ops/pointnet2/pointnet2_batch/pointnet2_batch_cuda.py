@@ -97,7 +97,20 @@ def farthest_point_sampling_buckets_wrapper(b, n, m, points, temp, idx):
     return 1
 
 
+def three_nn_grid_wrapper(b, n, m, unknown, grid, dist2, idx):
+    """three_nn through a cell grid over the known points (csrc/ball_query_grid.hip, three_nn_grid_kernel)."""
+    L.call("mgar_three_nn_grid_batch", b, n, m, L.fptr(unknown), L.fptr(grid.ws), L.fptr(dist2), L.iptr(idx), L.stream_of(unknown))
+    return 1
+
+
 def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    from ..... import point_grid as G
+    if G.ENABLED and m >= G.MIN_POINTS_PER_CLOUD and b > 0 and n > 0:
+        return three_nn_grid_wrapper(b, n, m, unknown, G.PointGrid(known, 0.0), dist2, idx)
+    return three_nn_scan_wrapper(b, n, m, unknown, known, dist2, idx)
+
+
+def three_nn_scan_wrapper(b, n, m, unknown, known, dist2, idx):
     L.call("mgar_three_nn_batch", b, n, m, L.fptr(unknown), L.fptr(known), L.fptr(dist2), L.iptr(idx),
            L.stream_of(unknown))
     return 1

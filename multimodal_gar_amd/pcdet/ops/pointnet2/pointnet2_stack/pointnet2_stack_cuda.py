@@ -96,7 +96,21 @@ def group_points_grad_wrapper(B, M, C, N, nsample, grad_out, idx, idx_batch_cnt,
     return 1
 
 
+def three_nn_grid_wrapper(unknown, unknown_batch_cnt, grid, dist2, idx):
+    """three_nn through a cell grid over the known points (csrc/ball_query_grid.hip, three_nn_grid_kernel)."""
+    L.call("mgar_three_nn_grid_stack", unknown_batch_cnt.shape[0], unknown.shape[0], grid.n_total, L.fptr(unknown),
+           L.iptr(unknown_batch_cnt), L.fptr(grid.ws), L.fptr(dist2), L.iptr(idx), L.stream_of(unknown))
+
+
 def three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+    from ..... import point_grid as G
+    b = unknown_batch_cnt.shape[0]
+    if known.is_cuda and b > 0 and unknown.shape[0] > 0 and G.ENABLED and known.shape[0] // b >= G.MIN_POINTS_PER_CLOUD:
+        return three_nn_grid_wrapper(unknown, unknown_batch_cnt.int(), G.PointGrid(known, 0.0, known_batch_cnt.int()), dist2, idx)
+    return three_nn_scan_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx)
+
+
+def three_nn_scan_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
     L.call("mgar_three_nn_stack", unknown_batch_cnt.shape[0], unknown.shape[0], known.shape[0], L.fptr(unknown),
            L.iptr(unknown_batch_cnt), L.fptr(known), L.iptr(known_batch_cnt), L.fptr(dist2), L.iptr(idx),
            L.stream_of(unknown))

@@ -111,3 +111,60 @@ def test_grid_equals_scan_kernel_at_c3_roi_size():
         assert torch.equal(a_, b_)
     print("RoI-grid ball queries, 4 frames x 3 radii: grid (incl. build) %.3f ms, scan %.3f ms" % tuple(times))
     assert times[0] < times[1]
+
+
+# ---------------------------------------------------------------------------------------------------- three_nn through the grid
+def _three_nn_grid_batch(unknown, known, cell=0.0):
+    from multimodal_gar_amd import point_grid as G
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as CB
+    b, n, _ = unknown.shape
+    m = known.shape[1]
+    d = torch.empty((b, n, 3), dtype=torch.float32, device="cuda")
+    i = torch.empty((b, n, 3), dtype=torch.int32, device="cuda")
+    CB.three_nn_grid_wrapper(b, n, m, dev(unknown), G.PointGrid(dev(known), cell), d, i)
+    return d.cpu().numpy(), i.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,m", [(4000, 2048), (16384, 4096), (3000, 9000), (500, 2100)])
+def test_grid_three_nn_batch_matches_oracle(oracle, n, m):
+    sc = _scene(n + m, 2, max(n, m))
+    unknown = np.ascontiguousarray(sc[:, :n])
+    known = np.ascontiguousarray(sc[:, -m:] + 0.013)
+    unknown[:, :6] = [[500, 500, 500], [-700, 3, 1], [0, 0, 90], [25, -25, 3], [-1e5, 0, 0], [20, 20, 2]]   # far outside the known cloud
+    want_d, want_i = oracle.three_nn_batch(unknown, known)
+    for cell in (0.0, -1.0, 0.3, 5.0):                       # automatic (4 / 1 point per cell) and fixed cell edges
+        got_d, got_i = _three_nn_grid_batch(unknown, known, cell)
+        np.testing.assert_array_equal(got_i, want_i)
+        np.testing.assert_array_equal(got_d, want_d)
+
+
+def test_grid_three_nn_ties_and_degenerate_clouds(oracle):
+    rng = np.random.default_rng(4)
+    lattice = rng.integers(-6, 7, (1, 3000, 3)).astype(np.float32)            # equal distances everywhere: the index decides
+    one = np.tile(np.array([[2.0, 1.0, -1.0]], np.float32), (1, 2500, 1))
+    line = np.zeros((1, 2500, 3), np.float32); line[0, :, 1] = np.linspace(-40, 40, 2500)
+    for known in (lattice, one, line):
+        unknown = np.concatenate([known[:, :400] + 0.5, known[:, 400:800], rng.uniform(-50, 50, (1, 200, 3)).astype(np.float32)], 1)
+        want_d, want_i = oracle.three_nn_batch(unknown, known)
+        got_d, got_i = _three_nn_grid_batch(unknown, known)
+        np.testing.assert_array_equal(got_i, want_i)
+        np.testing.assert_array_equal(got_d, want_d)
+
+
+def test_grid_three_nn_stack_ragged_matches_oracle(oracle):
+    from multimodal_gar_amd import point_grid as G
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_stack_cuda as CS
+    sc = _scene(21, 3, 7000)
+    kcnt = np.array([5000, 2, 0, 3000], np.int32)                         # fewer than three known points; none at all
+    known = np.concatenate([sc[0][:5000], sc[1][:2], sc[2][:3000]])
+    ucnt = np.array([800, 50, 20, 0], np.int32)
+    unknown = np.concatenate([sc[0][5000:5800], sc[1][100:150], sc[2][4000:4020]]).astype(np.float32)
+    want_d, want_i = oracle.three_nn_stack(unknown, ucnt, known, kcnt)
+    d = torch.empty((unknown.shape[0], 3), dtype=torch.float32, device="cuda")
+    i = torch.empty((unknown.shape[0], 3), dtype=torch.int32, device="cuda")
+    CS.three_nn_grid_wrapper(dev(unknown), dev(ucnt), G.PointGrid(dev(known), 0.0, dev(kcnt)), d, i)
+    np.testing.assert_array_equal(i.cpu().numpy(), want_i)
+    np.testing.assert_array_equal(d.cpu().numpy(), want_d)
+    d2, i2 = torch.empty_like(d), torch.empty_like(i)
+    CS.three_nn_scan_wrapper(dev(unknown), dev(ucnt), dev(known), dev(kcnt), d2, i2)
+    assert torch.equal(i, i2) and torch.equal(d, d2)
