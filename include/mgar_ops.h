@@ -602,6 +602,8 @@ int mgar_spconv_dw_chunks(int No);
  * mgar_spconv_pair_chunk() pairs each, grouped by ascending offset; item_start (K + 1) int32: first item of every offset.
  * partial (n_items, Cin, Cout) scratch; dw (K, Cin, Cout) fully written, summed in item order (reproducible).
  * C_in, C_out powers of two <= 128 (MGAR_EUNSUPPORTED otherwise: mgar_spconv_dw). */
+int mgar_spconv_set_register_gather(int on);   /* A/B switch of mgar_spconv_gather_gemm: 1 (default) = the register-gather kernel
+                                               * (spconv_os_kernel) where it applies, 0 = always the LDS-staged kernel */
 int mgar_spconv_pair_chunk(void);
 /* The pair lists themselves, built on the device from the neighbour table nbr (No, K) (round 3; replaces six torch passes):
  * mgar_spconv_pairs_count fills blk (K, mgar_spconv_pairs_blocks(No)) int32 (per-row-block counts, scanned per offset) and total (K)

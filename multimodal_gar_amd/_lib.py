@@ -130,6 +130,7 @@ _PROTOS = {
     "mgar_spconv_gather_gemm": [_I, _I, _I, _I, _P, _P, _P, _I, _P, _P],
     "mgar_spconv_dw_chunks": [_I],
     "mgar_spconv_pair_chunk": [],
+    "mgar_spconv_set_register_gather": [_I],
     "mgar_spconv_pairs_blocks": [_I],
     "mgar_spconv_pairs_count": [_I, _I, _P, _P, _P, _P],
     "mgar_spconv_pairs_fill": [_I, _I, _P, _P, _P, _P, _P, _P],

@@ -188,6 +188,115 @@ __global__ __launch_bounds__(256) void spconv_gather_gemm_kernel(int No, int K, 
     }
 }
 
+// ---- output-stationary gather-GEMM with the gathered rows in REGISTERS (round 3) -------------------------------------------------
+// spconv_gather_gemm_kernel stages every offset's 64 gathered rows AND W_k through LDS between two barriers, with nothing in
+// flight while it multiplies: 5 ms per 64-channel layer at config c3 (21 TFLOP/s).  Here a wave owns 32 output rows for the whole
+// kernel and the MFMA's A operand comes straight from global memory:
+//   * v_mfma_f32_32x32x2_f32 sums over a k index whose ORDER is free as long as A and B agree.  With k = h * (C_in / 2) + s
+//     (h = lane / 32, s = step) lane (l, h) needs elements [h * C_in / 2, (h + 1) * C_in / 2) of the gathered row of output row l:
+//     one contiguous run -- C_in / 8 16-byte loads, no LDS round trip, no transposition;
+//   * the rows of offset k + 1 (and the table entry of k + 2) are in flight while offset k is multiplied;
+//   * W_k goes through a double-buffered LDS tile filled by all four waves (one barrier per offset); lanes read it with unit
+//     stride along the output channel (conflict-free).
+// Same sums in another order (rows with no neighbour contribute zeros), so results agree with the LDS kernel to fp32 rounding.
+// CINP: C_in rounded up to {4, 16, 32, 64, 128}; NCB: 32-column blocks of the output (C_out <= 32 * NCB).
+template <int CINP, int NCB>
+__global__ __launch_bounds__(256) void spconv_os_kernel(int No, int K, int Cin, int Cout, const float *__restrict__ in,
+                                                        const int *__restrict__ nbr, const float *__restrict__ w, int flip_k,
+                                                        float *__restrict__ out) {
+    constexpr int CH = CINP / 2;                 // k steps per MFMA half = elements of its row a lane holds
+    constexpr int COUTP = NCB * 32;
+    constexpr int WPT = CINP * COUTP / 256;      // floats of W_k each thread stages (>= 1 for every instantiation)
+    __shared__ float Wl[2][CINP * COUTP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = lane & 31, h = lane >> 5;
+    const int row = blockIdx.x * 128 + wave * 32 + l;
+    const bool rok = row < No;
+    const int *__restrict__ nrow = nbr + (size_t)(rok ? row : 0) * K;
+    f32x16 acc[NCB];
+#pragma unroll
+    for (int a = 0; a < NCB; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    float areg0[CH], areg1[CH];                  // the gathered rows of the current / next offset (two named arrays: static register indices)
+    float wreg[WPT];
+    auto load_w = [&](int k) {
+        const float *wk = w + (size_t)(flip_k ? K - 1 - k : k) * Cin * Cout;
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) {
+            const int e = q * 256 + threadIdx.x;
+            const int ci = e / COUTP, co = e - ci * COUTP;
+            wreg[q] = (ci < Cin && co < Cout) ? wk[(size_t)ci * Cout + co] : 0.f;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) Wl[buf][q * 256 + threadIdx.x] = wreg[q];
+    };
+    auto load_a = [&](float (&dst)[CH], int j) {
+        if (j >= 0) {
+            const float *src = in + (size_t)j * Cin + h * CH;
+            if constexpr (CH % 4 == 0) {
+                if (Cin == CINP) {
+#pragma unroll
+                    for (int q = 0; q < CH / 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+                        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+                    }
+                    return;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) dst[q] = (h * CH + q < Cin) ? src[q] : 0.f;
+        } else {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) dst[q] = 0.f;
+        }
+    };
+    int j_next = -1;
+    // one offset: rows of offset k are in `cur`, W_k in Wl[buf]; fetch offset k + 1 into `nxt` / the other W buffer meanwhile
+    auto step = [&](int k, int buf, float (&cur)[CH], float (&nxt)[CH]) {
+        const int j1 = j_next;
+        if (k + 1 < K) {
+            load_w(k + 1);                                    // in flight during the MFMAs below
+            j_next = (rok && k + 2 < K) ? nrow[k + 2] : -1;
+            load_a(nxt, j1);
+        }
+        const float *Wk = Wl[buf];
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const float av = cur[s];
+#pragma unroll
+            for (int a = 0; a < NCB; ++a) {
+                const float bv = Wk[(h * CH + s) * COUTP + a * 32 + l];
+                acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+            }
+        }
+        if (k + 1 < K) store_w(buf ^ 1);
+        __syncthreads();                                      // W_{k+1} visible; W_k's buffer is free for offset k + 2
+    };
+    // prologue: W_0 -> LDS, rows of offset 0 -> registers, table entry of offset 1
+    load_w(0);
+    j_next = (rok && K > 1) ? nrow[1] : -1;
+    load_a(areg0, rok ? nrow[0] : -1);
+    store_w(0);
+    __syncthreads();
+    for (int k = 0; k < K; k += 2) {
+        step(k, 0, areg0, areg1);
+        if (k + 1 < K) step(k + 1, 1, areg1, areg0);
+    }
+    const int obase = blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int a = 0; a < NCB; ++a) {
+        const int co = a * 32 + l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = obase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (orow < No && co < Cout) out[(size_t)orow * Cout + co] = acc[a][r];
+        }
+    }
+}
+
 // ---- weight gradient: dW[k] (Cin, Cout) = sum_o in[nbr[o, k], :]^T dout[o, :] ----------------------------------------------
 // grid (K, nchunk) -- the K workgroups of one row chunk are neighbours in launch order, so the chunk's dout rows and the input
 // rows around it are fetched from HBM once and then served by L2 / MALL to the other offsets;
@@ -505,30 +614,50 @@ static bool sp_geom_ok(const int *g) {
 // nbr (No, K) -> for every offset k the (input row, output row) pairs with a neighbour, ascending output row, offsets one after
 // another: pair_i / pair_o (P).  Three launches instead of the six torch passes (mask, transpose, sum, nonzero, two index
 // gathers: ~10 ms per rulebook at 4 M sites):
-//   sp_pairs_count_kernel  a workgroup owns SP_PB consecutive rows: per offset, how many of them have a neighbour -> blk (K, nblk)
+//   sp_pairs_count_kernel  a workgroup owns SP_PB consecutive rows (its tile of the table staged in LDS): per offset, how many of them
+//                          have a neighbour -> blk (K, nblk)
 //   sp_pairs_scan_kernel   one workgroup per offset: exclusive scan over the row blocks (in place) + the offset's total
 //   sp_pairs_fill_kernel   the same workgroups rank their rows per offset (ballot prefix inside a wave, the waves in order) and write
 //                          the pairs at  offset_start[k] + blk[k][b] + rank  -- stable: ascending output row, deterministic.
-constexpr int SP_PB = 1024;   // rows per workgroup (256 lanes x 4 row groups)
+constexpr int SP_PB = 512;    // rows per workgroup: 4 waves x 2 groups of 64 rows; the (SP_PB, K) tile of the table is staged in LDS
+constexpr int SP_PG = SP_PB / 64;   // 64-row groups per workgroup (group g belongs to wave g / 2)
 
-__global__ __launch_bounds__(256) void sp_pairs_count_kernel(int No, int K, const int *__restrict__ nbr, int *__restrict__ blk) {
-    extern __shared__ int lcnt[];   // K counters
-    const int b = blockIdx.x, nblk = gridDim.x;
-    for (int k = threadIdx.x; k < K; k += 256) lcnt[k] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
+// the workgroup's (rows, K) tile of the neighbour table -> LDS with coalesced reads (the per-offset passes below read it with a
+// stride of K words: conflict-free for odd K, and never from global memory)
+__device__ __forceinline__ void sp_pairs_stage(int No, int K, int row0, const int *__restrict__ nbr, int *__restrict__ tile) {
+    const long long base = (long long)row0 * K;
+    const int n = min(SP_PB, No - row0) * K;
+    for (int e = threadIdx.x; e < SP_PB * K; e += 256) tile[e] = e < n ? nbr[base + e] : -1;
+}
+
+// gcnt[g * K + k] = rows of 64-row group g with a neighbour under offset k
+__device__ __forceinline__ void sp_pairs_group_counts(int K, const int *__restrict__ tile, int *__restrict__ gcnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int g = 0; g < SP_PB / 256; ++g) {
-        const int row = b * SP_PB + g * 256 + threadIdx.x;
-        const int *r = nbr + (size_t)row * K;
+    for (int gg = 0; gg < 2; ++gg) {
+        const int g = wave * 2 + gg;
+        const int *r = tile + (g * 64 + lane) * K;
         for (int k = 0; k < K; ++k) {
-            const bool has = row < No && r[k] >= 0;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
-            if (lane == 0 && m) atomicAdd(&lcnt[k], __builtin_popcountll(m));
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(r[k] >= 0);
+            if (lane == 0) gcnt[g * K + k] = __builtin_popcountll(m);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void sp_pairs_count_kernel(int No, int K, const int *__restrict__ nbr, int *__restrict__ blk) {
+    extern __shared__ int lds_i[];   // tile [SP_PB][K], gcnt [SP_PG][K]
+    int *tile = lds_i, *gcnt = lds_i + SP_PB * K;
+    const int b = blockIdx.x, nblk = gridDim.x;
+    sp_pairs_stage(No, K, b * SP_PB, nbr, tile);
     __syncthreads();
-    for (int k = threadIdx.x; k < K; k += 256) blk[(size_t)k * nblk + b] = lcnt[k];
+    sp_pairs_group_counts(K, tile, gcnt);
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        int t = 0;
+#pragma unroll
+        for (int g = 0; g < SP_PG; ++g) t += gcnt[g * K + k];
+        blk[(size_t)k * nblk + b] = t;
+    }
 }
 
 __global__ __launch_bounds__(1024) void sp_pairs_scan_kernel(int nblk, int *__restrict__ blk, int *__restrict__ total) {
@@ -555,31 +684,31 @@ __global__ __launch_bounds__(1024) void sp_pairs_scan_kernel(int nblk, int *__re
 __global__ __launch_bounds__(256) void sp_pairs_fill_kernel(int No, int K, const int *__restrict__ nbr, const int *__restrict__ blk,
                                                             const long long *__restrict__ offset_start, int *__restrict__ pair_i,
                                                             int *__restrict__ pair_o) {
-    extern __shared__ int lrun[];   // K running ranks inside this workgroup
-    __shared__ int wcnt[4];
+    extern __shared__ int lds_i[];   // tile [SP_PB][K], gcnt [SP_PG][K]
+    int *tile = lds_i, *gcnt = lds_i + SP_PB * K;
     const int b = blockIdx.x, nblk = gridDim.x;
-    for (int k = threadIdx.x; k < K; k += 256) lrun[k] = 0;
+    const int row0 = b * SP_PB;
+    sp_pairs_stage(No, K, row0, nbr, tile);
+    __syncthreads();
+    sp_pairs_group_counts(K, tile, gcnt);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int g = 0; g < SP_PB / 256; ++g) {
-        const int row = b * SP_PB + g * 256 + threadIdx.x;
-        const int *r = nbr + (size_t)row * K;
+#pragma unroll
+    for (int gg = 0; gg < 2; ++gg) {
+        const int g = wave * 2 + gg;
+        const int row = row0 + g * 64 + lane;
+        const int *r = tile + (g * 64 + lane) * K;
         for (int k = 0; k < K; ++k) {
-            const int v = row < No ? r[k] : -1;
-            const bool has = v >= 0;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
-            if (lane == 0) wcnt[wave] = __builtin_popcountll(m);
-            __syncthreads();
-            int before = lrun[k];
-            for (int w = 0; w < wave; ++w) before += wcnt[w];
-            const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];   // read before the barrier below: the next offset overwrites wcnt
-            if (has) {
+            const int v = r[k];
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(v >= 0);
+            if (m == 0ull) continue;                     // wave-uniform
+            int before = 0;
+            for (int q = 0; q < g; ++q) before += gcnt[q * K + k];   // the groups in front of this one (ascending rows)
+            if (v >= 0) {
                 const long long pos = offset_start[k] + blk[(size_t)k * nblk + b] + before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
                 pair_i[pos] = v;
                 pair_o[pos] = row;
             }
-            __syncthreads();
-            if (threadIdx.x == 0) lrun[k] += all;
         }
     }
 }
@@ -589,6 +718,10 @@ __global__ __launch_bounds__(256) void sp_pairs_fill_kernel(int No, int K, const
 using namespace mgar;
 
 #define SP_API extern "C" __attribute__((visibility("default")))
+
+static int g_spconv_os = 1;
+// A/B switch (tests, profiles): 1 = register-gather kernel where it applies (default), 0 = always the LDS kernel
+SP_API int mgar_spconv_set_register_gather(int on) { g_spconv_os = on ? 1 : 0; return MGAR_OK; }
 
 // Hash table over the voxel coordinates coords (N, 4) int32 [b, z, y, x] of a (Z, Y, X) grid.  table_keys (capacity) int64
 // must be pre-filled with -1 and table_vals (capacity) int32 with INT_MAX by the caller; capacity a power of two >= 2 N.
@@ -668,6 +801,30 @@ SP_API int mgar_spconv_gather_gemm(int No, int K, int Cin, int Cout, const float
     }
     if (No == 0) return MGAR_OK;
     MGAR_REQUIRE(in && nbr && w && out, "spconv_gather_gemm: null pointer");
+    {
+        // register-gather kernel (spconv_os_kernel) for the channel counts of VoxelBackBone8x; anything else: the LDS kernel below
+        const int cinp = Cin <= 4 ? 4 : (Cin <= 16 ? 16 : (Cin <= 32 ? 32 : (Cin <= 64 ? 64 : 128)));
+        const int ncb = (Cout + 31) / 32;
+        const bool aligned = (Cin == cinp ? (reinterpret_cast<uintptr_t>(in) & 15) == 0 : true);
+        hipStream_t st = (hipStream_t)stream;
+        const dim3 grid(ceil_div(No, 128));
+#define SP_OS(CI, NB)                                                                                                        \
+        do {                                                                                                                     \
+            KtScope kt(KT_SPCONV_GEMM, st, 4.0 * No * ((double)K + Cout) + 4.0 * (double)K * Cin * Cout);                        \
+            hipLaunchKernelGGL((spconv_os_kernel<CI, NB>), grid, dim3(256), 0, st, No, K, Cin, Cout, in, nbr, w, flip_k, out);    \
+            return check_launch("spconv_gather_gemm: launch failed");                                                            \
+        } while (0)
+        if (g_spconv_os && aligned && cinp * ncb * 32 >= 256 && cinp * ncb * 32 * 8 <= 64 * 1024) {
+            if (cinp == 16 && ncb == 1) SP_OS(16, 1);
+            if (cinp == 32 && ncb == 1) SP_OS(32, 1);
+            if (cinp == 32 && ncb == 2) SP_OS(32, 2);
+            if (cinp == 64 && ncb == 1) SP_OS(64, 1);
+            if (cinp == 64 && ncb == 2) SP_OS(64, 2);
+            if (cinp == 128 && ncb == 2) SP_OS(128, 2);
+            if (cinp == 16 && ncb == 2) SP_OS(16, 2);
+        }
+#undef SP_OS
+    }
     const int CoutP = (Cout + 31) & ~31, CinP = (Cin + 1) & ~1;
     const size_t lds = ((size_t)SC_ROWS * K + (size_t)SC_ROWS * (CinP + 1) + (size_t)CinP * CoutP) * sizeof(float);
     MGAR_REQUIRE(lds <= 160 * 1024, "spconv_gather_gemm: tile does not fit LDS");
@@ -798,7 +955,10 @@ SP_API int mgar_spconv_pairs_count(int No, int K, const int *nbr, int *blk, int 
     MGAR_REQUIRE(nbr && blk, "spconv_pairs_count: null pointer");
     const int nblk = (No + SP_PB - 1) / SP_PB;
     KtScope kt(KT_SPCONV_INDEX, st, 4.0 * (double)No * K);
-    hipLaunchKernelGGL(sp_pairs_count_kernel, dim3(nblk), dim3(256), K * sizeof(int), st, No, K, nbr, blk);
+    const size_t lds = (size_t)(SP_PB + SP_PG) * K * sizeof(int);
+    MGAR_REQUIRE(lds <= 160 * 1024, "spconv_pairs_count: K too large for the LDS tile");
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)sp_pairs_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sp_pairs_count_kernel, dim3(nblk), dim3(256), lds, st, No, K, nbr, blk);
     hipLaunchKernelGGL(sp_pairs_scan_kernel, dim3(K), dim3(1024), 0, st, nblk, blk, total);
     return check_launch("spconv_pairs_count: launch failed");
 }
@@ -810,6 +970,9 @@ SP_API int mgar_spconv_pairs_fill(int No, int K, const int *nbr, const int *blk,
     hipStream_t st = (hipStream_t)stream;
     const int nblk = (No + SP_PB - 1) / SP_PB;
     KtScope kt(KT_SPCONV_INDEX, st, 4.0 * (double)No * K + 8.0 * (double)No * K / 3.0);
-    hipLaunchKernelGGL(sp_pairs_fill_kernel, dim3(nblk), dim3(256), K * sizeof(int), st, No, K, nbr, blk, offset_start, pair_i, pair_o);
+    const size_t lds = (size_t)(SP_PB + SP_PG) * K * sizeof(int);
+    MGAR_REQUIRE(lds <= 160 * 1024, "spconv_pairs_fill: K too large for the LDS tile");
+    if (lds > 65536) (void)hipFuncSetAttribute((const void *)sp_pairs_fill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sp_pairs_fill_kernel, dim3(nblk), dim3(256), lds, st, No, K, nbr, blk, offset_start, pair_i, pair_o);
     return check_launch("spconv_pairs_fill: launch failed");
 }

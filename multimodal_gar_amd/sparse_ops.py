@@ -8,6 +8,8 @@ Semantics (published definition of the two layers; spconv itself is neither vend
   SparseConv3d : output sites = every o in the output grid with at least one active input under its kernel, listed in
                  ascending (b, z, y, x) order; output grid = floor((in + 2 pad - k) / stride) + 1.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -194,7 +196,10 @@ def _pairs_gemm(rb, n_dst, src_feats, w, transpose):
 
 
 PAIRS_FORWARD = False    # forward over pair lists (False: the table-driven, output-stationary gather-GEMM -- no read-modify-write)
-PAIRS_DGRAD = True       # data gradient over pair lists (no inverse table)
+# data gradient: over pair lists (27 per-offset launches with read-modify-write, no inverse table), or table-driven on the
+# register-gather kernel (one launch, no read-modify-write; a strided convolution needs its inverse table: one more rulebook
+# launch).  MGAR_SPCONV_DGRAD=pairs|table overrides (A/B in profiles/).
+PAIRS_DGRAD = os.environ.get("MGAR_SPCONV_DGRAD", "table") == "pairs"
 
 
 class _SparseConv(Function):

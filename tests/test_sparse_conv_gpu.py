@@ -227,3 +227,38 @@ def test_device_pair_list_builder_equals_the_torch_definition(subm, kernel, stri
     offs = np.concatenate([[0], np.cumsum(counts.cpu().numpy())])
     for k, b, e, _ in it:
         assert offs[k] <= b < e <= offs[k + 1]
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 64), (24, 40)])
+@pytest.mark.parametrize("flip", [0, 1])
+def test_register_gather_kernel_equals_lds_kernel(cin, cout, flip):
+    """spconv_os_kernel (gathered rows straight into the MFMA's A registers, double-buffered W in LDS; round 3) against the
+    LDS-staged spconv_gather_gemm_kernel on the same table: same sums in another order.  Ragged last tile, rows without any
+    neighbour, mirrored offsets (the submanifold data gradient); (24, 40) falls outside the register kernel's channel table and
+    must take the LDS kernel either way."""
+    from multimodal_gar_amd import _lib as L, sparse_ops
+    shape, batch = [10, 36, 40], 2
+    idx = sparse_sites(3, batch, tuple(shape), 0.12).cuda()
+    rb = sparse_ops.Rulebook(idx, shape, batch, 3, 1, 1, True)
+    n = idx.shape[0]
+    assert n % 128 != 0 and n > 2000
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    feats = torch.randn(n, cin, generator=g).cuda()
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5).cuda()
+    outs = []
+    for on in (1, 0):
+        L.call("mgar_spconv_set_register_gather", on)
+        try:
+            outs.append(sparse_ops._gather_gemm(n, 27, cin, cout, feats, rb.nbr, w, flip))
+        finally:
+            L.call("mgar_spconv_set_register_gather", 1)
+    a, b = outs
+    assert (a - b).abs().max().item() <= 2e-5 * (b.abs().max().item() + 1e-6)
+    # and against the definition in float64
+    nb = rb.nbr.long()
+    want = torch.zeros(n, cout, dtype=torch.float64, device="cuda")
+    for k in range(27):
+        wk = w[26 - k if flip else k].double()
+        has = nb[:, k] >= 0
+        want[has] += feats[nb[has, k]].double() @ wk
+    assert (a.double() - want).abs().max().item() <= 2e-5 * (want.abs().max().item() + 1e-6)
