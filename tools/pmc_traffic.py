@@ -27,7 +27,11 @@ KERNELS = {
     "bn_max_bwd_partial_kernel": "mgar::bn_max_bwd_partial_kernel", "bn_max_bwd_apply_kernel": "mgar::bn_max_bwd_apply_kernel",
     "pointwise_fwd_kernel": "mgar::pointwise_fwd_kernel", "pointwise_dw_kernel": "mgar::pointwise_dw_kernel<",
     "rowmajor_dw_kernel": "mgar::rowmajor_dw_kernel", "maxpool3d_same_kernel": "mgar::maxpool3d_same",
-    "fps_kernel": "mgar::fps_", "ball_query_kernel": "mgar::ball_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
+    "fps_kernel": "mgar::fps_", "ball_query_kernel": "mgar::ball_query_kernel", "ball_query_grid_kernel": "mgar::ball_query_grid_kernel",
+    "three_nn_grid_kernel": "mgar::three_nn_grid_kernel", "point_grid_build": "mgar::pg_", "spconv_gemm": "mgar::spconv_os_kernel",
+    "spconv_dw": "mgar::spconv_pairs_dw_kernel", "spconv_index": "mgar::sp_", "gatv2_bwd": "mgar::gatv2_bwd_", "gatv2_fwd": "mgar::gatv2_fwd_kernel",
+    "dafm_attn_fwd": "mgar::dafm_fwd_kernel", "dafm_attn_bwd": "mgar::dafm_bwd_", "roi_align_fwd": "mgar::roi_align_fwd_kernel",
+    "roi_align_bwd": "mgar::roi_align_bwd_kernel", "voxel_query_kernel": "mgar::voxel_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
     "three_interp_fwd": "mgar::three_interp_batch_fwd", "three_interp_bwd": "mgar::three_interp_batch_bwd",
     "query_group_fwd": "mgar::qg_", "query_group_bwd": "mgar::qg_", "query_group_inverse_index": "mgar::qg_inv_",
     "stem_conv3d_kernel": "mgar::stem_conv3d_kernel", "voxel_roi_pool_fwd": "mgar::vrp_fwd_kernel", "voxel_roi_pool_bwd": "mgar::vrp_bwd_kernel",
