@@ -1,11 +1,8 @@
 from .pointnet2_backbone import PointNet2MSG
 from .spconv_backbone import VoxelBackBone8x
-from .voxel_pyramid import SparseTensorLite, VoxelPyramidStandIn
 
 __all__ = {
     'PointNet2MSG': PointNet2MSG,
     # the reference's sparse trunk (spconv_backbone.py:69-170) on this repo's sparse-convolution kernels
     'VoxelBackBone8x': VoxelBackBone8x,
-    # round-1 placeholder (average pooling + Linear), kept for A/B runs only
-    'VoxelPyramidStandIn': VoxelPyramidStandIn,
 }

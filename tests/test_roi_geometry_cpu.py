@@ -22,7 +22,7 @@ def test_grid_points_of_roi_match_numpy():
 
 def test_voxel_centers_voxel2pinds_meanvfe():
     from multimodal_gar_amd.pcdet.utils import common_utils as cu
-    from multimodal_gar_amd.pcdet.models.backbones_3d.voxel_pyramid import SparseTensorLite
+    from multimodal_gar_amd.pcdet.utils.spconv_utils import SparseConvTensor as SparseTensorLite
     from multimodal_gar_amd.pcdet.models.backbones_3d.vfe import MeanVFE
     coords = torch.tensor([[0, 1, 2], [3, 0, 5]])                      # z, y, x
     centres = cu.get_voxel_centers(coords, 2, [0.1, 0.2, 0.5], [-1.0, -2.0, -3.0, 1, 2, 3])
