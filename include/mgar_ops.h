@@ -471,6 +471,13 @@ int mgar_pointwise_conv_fwd_stats(const float *x, int B, int Cin, int P, const f
  * ceil(H/sh), ceil(W/sw)).  Forward only (I3D is frozen in MGAR-net). */
 int mgar_maxpool3d_same_fwd(const float *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh,
                             int sw, float *y, void *stream);
+/* The same windows with the maximum taken over their VALID elements only (the padding does not take part): for pooling a
+ * PRE-BatchNorm tensor.  With gamma > 0 in every channel, maxpool_same(relu(bn(x))) == relu(bn(maxpool_valid(x))) bit for bit
+ * (monotone per channel, relu >= 0 absorbs the zero padding), so a Unit3D that feeds a MaxPool3dSamePadding
+ * (model/backbone.py:305-313: Conv3d_1a_7x7 -> MaxPool3d_2a_3x3, Conv3d_2c_3x3 -> MaxPool3d_3a_3x3) normalises the pooled
+ * tensor instead of the full one. */
+int mgar_maxpool3d_valid_fwd(const float *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, float *y,
+                             void *stream);
 
 /* The first convolution of Inception-I3D (model/backbone.py:305-307 ``Conv3d_1a_7x7``: Unit3D(3 -> 64, kernel [7,7,7],
  * stride (2,2,2), TF "same" padding :168-172, no bias) as a direct implicit GEMM on the fp32 MFMA: padding handled in the
@@ -747,6 +754,8 @@ int mgar_three_interpolate_stack_bf16(int N, int C, const void *features, const 
 /* x, y */
 int mgar_maxpool3d_same_fwd_bf16(const void *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh,
                                  int sw, void *y, void *stream);
+int mgar_maxpool3d_valid_fwd_bf16(const void *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, void *y,
+                                  void *stream);
 /* input, out (rois fp32) */
 int mgar_roi_align_fwd_bf16(const void *input, int N, int C, int H, int W, const float *rois, int K,
                             int pooled_h, int pooled_w, float spatial_scale, int sampling_ratio, int aligned,

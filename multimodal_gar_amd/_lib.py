@@ -109,6 +109,7 @@ _PROTOS = {
     "mgar_stem_conv3d_workspace_floats": [],
     "mgar_stem_conv3d_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_maxpool3d_same_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "mgar_maxpool3d_valid_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_roi_align_bwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
     "mgar_dafm_attn_fwd": [_I, _I, _I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P],
@@ -149,7 +150,7 @@ for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_que
            "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_small", "mgar_bn_cl_train_stats", "mgar_bn_cl_act_fwd", "mgar_bn_act_fwd_to_cl",
            "mgar_maxpool3d_same_fwd_cl", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
            "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_batch_into", "mgar_three_interpolate_stack",
-           "mgar_maxpool3d_same_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
+           "mgar_maxpool3d_same_fwd", "mgar_maxpool3d_valid_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]
 BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))
 

@@ -553,6 +553,47 @@ def bn_act_per_sample(x, bn, relu, out=None, to_channels_last=False):
     return y.view(x.shape)
 
 
+def bn_train_stats_only(x, bn, per_sample=False):
+    """Batch statistics (mean, invstd) of x (G, C, ...) for a train-mode ``bn`` -- running statistics and the batch counter
+    updated exactly as a forward pass does -- without applying anything; per_sample: every sample its own statistics, (G * C)
+    vectors.  None where the grouped kernel does not apply."""
+    x3 = x.contiguous().flatten(2)
+    g, c, p = x3.shape
+    if not per_sample:
+        return _train_stats(x3, bn)
+    if g * c > 65535:
+        return None
+    mean = torch.empty((g * c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    track = bn.track_running_stats and bn.running_mean is not None
+    ws = _workspace(x3, 1, g * c, p)
+    dt = x3.dtype
+    L.payload_call("mgar_bn_train_stats_grouped", dt, L.pptr(x3, dt), g, c, p, float(bn.eps),
+                   float(bn.momentum if bn.momentum is not None else 0.1),
+                   L.fptr(ws), L.fptr(mean), L.fptr(invstd), L.fptr(bn.running_mean) if track else None,
+                   L.fptr(bn.running_var) if track else None,
+                   L.dev_ptr(bn.num_batches_tracked, torch.int64) if track and bn.num_batches_tracked is not None else None, L.stream_of(x3))
+    return mean, invstd
+
+
+def bn_apply_with_stats(x, bn, relu, stats, per_sample=False):
+    """[relu]((x - mean) * invstd * gamma + beta) with GIVEN statistics (forward only): x may be a different tensor than the one
+    the statistics were taken from (Unit3D.forward_then_pool: the pooled tensor)."""
+    mean, invstd = stats
+    x3 = x.contiguous().flatten(2)
+    g, c, p = x3.shape
+    gamma, beta = _affine(bn, c, x.device)
+    y = torch.empty_like(x3)
+    dt = x3.dtype
+    if per_sample:
+        L.payload_call("mgar_bn_act_fwd_grouped", dt, L.pptr(x3, dt), g, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+                       int(relu), L.pptr(y, dt), L.stream_of(x3))
+    else:
+        L.payload_call("mgar_bn_act_fwd", dt, L.pptr(x3, dt), g, c, p, L.fptr(mean), L.fptr(invstd), L.fptr(gamma), L.fptr(beta),
+                       int(relu), L.pptr(y, dt), L.stream_of(x3))
+    return y.view(x.shape)
+
+
 def bn_act_maxpool(x, bn, relu, in_stats=None):
     """max over the last axis of [relu](bn(x)) for x (B, C, M, ns) -> (B, C, M).  in_stats: statistics partials of x left by
     its producer kernel (stats_partial_buffer)."""

@@ -21,6 +21,8 @@ namespace mgar {
 struct Pool3dGeom {
     int T, H, W, To, Ho, Wo;
     int kt, kh, kw, st, sh, sw, pt, ph, pw;  // p* = FRONT padding of each axis
+    int pad_zero;                            // 1: the zero padding takes part in the max (TF "same" on an activation); 0: max over the
+                                             // window's VALID elements only (pooling a PRE-BatchNorm tensor, see mgar_maxpool3d_valid_fwd)
 };
 
 template <typename T>   // payload type: float or bf16_t (max of widened values is exact: bf16 in, bf16 out loses nothing)
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(256) void maxpool3d_same_kernel(const T *__restrict
         const int t0 = to * g.st - g.pt, h0 = ho * g.sh - g.ph, w0 = wo * g.sw - g.pw;
         const int t1 = t0 + g.kt, h1 = h0 + g.kh, w1 = w0 + g.kw;
         const bool pad = t0 < 0 || h0 < 0 || w0 < 0 || t1 > g.T || h1 > g.H || w1 > g.W;
-        float best = pad ? 0.f : -__builtin_inff();  // zero padding takes part in the max
+        float best = (pad && g.pad_zero) ? 0.f : -__builtin_inff();  // zero padding takes part in the max
         const T *base = x + (size_t)nc * g.T * g.H * g.W;
         for (int t = max(t0, 0); t < min(t1, g.T); ++t)
             for (int h = max(h0, 0); h < min(h1, g.H); ++h) {
@@ -101,9 +103,11 @@ __global__ __launch_bounds__(256) void maxpool3d_same_vec_kernel(const T *__rest
             if (lo <= t - 1) { r.x = fmaxf(r.x, p1.x); r.y = fmaxf(r.y, p1.y); r.z = fmaxf(r.z, p1.z); r.w = fmaxf(r.w, p1.w); }
             if (lo <= t - 2) { r.x = fmaxf(r.x, p0.x); r.y = fmaxf(r.y, p0.y); r.z = fmaxf(r.z, p0.z); r.w = fmaxf(r.w, p0.w); }
             const bool pad = pad_h || t0 < 0 || t1 > g.T;  // zero padding takes part in the max wherever the window leaves the input
-            if (pad || pad_l) r.x = fmaxf(r.x, 0.f);
-            if (pad) { r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); }
-            if (pad || pad_r) r.w = fmaxf(r.w, 0.f);
+            if (g.pad_zero) {
+                if (pad || pad_l) r.x = fmaxf(r.x, 0.f);
+                if (pad) { r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); }
+                if (pad || pad_r) r.w = fmaxf(r.w, 0.f);
+            }
             Payload<T>::st4(y + ((nc * g.To + to) * g.Ho + ho) * g.Wo + wq * 4, r);
             ++to;
         }
@@ -116,7 +120,7 @@ using namespace mgar;
 
 template <typename T_>
 static int maxpool3d_same_fwd_impl(const T_ *x, int NC, int T, int H, int W, int kt, int kh, int kw, int st, int sh, int sw, T_ *y,
-                                   void *stream) {
+                                   void *stream, int pad_zero = 1) {
     MGAR_REQUIRE(NC >= 0 && T > 0 && H > 0 && W > 0 && kt > 0 && kh > 0 && kw > 0 && st > 0 && sh > 0 && sw > 0,
                  "maxpool3d_same_fwd: bad sizes");
     if (NC == 0) return MGAR_OK;
@@ -126,7 +130,7 @@ static int maxpool3d_same_fwd_impl(const T_ *x, int NC, int T, int H, int W, int
         return total / 2;
     };
     Pool3dGeom g{T, H, W, (T + st - 1) / st, (H + sh - 1) / sh, (W + sw - 1) / sw, kt, kh, kw, st, sh, sw,
-                 front(T, kt, st), front(H, kh, sh), front(W, kw, sw)};
+                 front(T, kt, st), front(H, kh, sh), front(W, kw, sw), pad_zero};
     KtScope ktimer(KT_MAXPOOL3D, (hipStream_t)stream, (double)sizeof(T_) * NC * ((double)T * H * W + (double)g.To * g.Ho * g.Wo));
     const bool vec1 = kw == 3 && sw == 1 && g.pw == 1, vec2 = kw == 3 && sw == 2 && g.pw == 0 && W % 2 == 0;
     if ((vec1 || vec2) && kt <= 3 && W % 4 == 0 && g.Wo % 4 == 0 && NC <= 65535 && (!vec2 || W >= 8)) {
@@ -149,4 +153,19 @@ extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_same_fwd_bf
                                                                                   int kh, int kw, int st, int sh, int sw, void *y,
                                                                                   void *stream) {
     return maxpool3d_same_fwd_impl<bf16_t>((const bf16_t *)x, NC, T, H, W, kt, kh, kw, st, sh, sw, (bf16_t *)y, stream);
+}
+
+// The same windows, maximum over the VALID elements only (no zero padding in the max): pooling a PRE-BatchNorm tensor.  With
+// gamma > 0, relu(bn(.)) is monotone non-decreasing per channel -- in fp32 too: subtract, multiply by a positive constant, add
+// and max(., 0) are all monotone -- and relu(.) >= 0 makes the zero padding a no-op, so
+//     maxpool_same(relu(bn(x))) == relu(bn(maxpool_valid(x)))     bit for bit,
+// and the BatchNorm + ReLU pass runs over the pooled tensor (1/4 ... 1/8 of the elements) instead of the full one.
+extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_valid_fwd(const float *x, int NC, int T, int H, int W, int kt, int kh,
+                                                                              int kw, int st, int sh, int sw, float *y, void *stream) {
+    return maxpool3d_same_fwd_impl<float>(x, NC, T, H, W, kt, kh, kw, st, sh, sw, y, stream, 0);
+}
+extern "C" __attribute__((visibility("default"))) int mgar_maxpool3d_valid_fwd_bf16(const void *x, int NC, int T, int H, int W, int kt,
+                                                                                   int kh, int kw, int st, int sh, int sw, void *y,
+                                                                                   void *stream) {
+    return maxpool3d_same_fwd_impl<bf16_t>((const bf16_t *)x, NC, T, H, W, kt, kh, kw, st, sh, sw, (bf16_t *)y, stream, 0);
 }

@@ -64,6 +64,18 @@ class MaxPool3dSamePadding(nn.MaxPool3d):
         pads = _same_pads(x.shape[2:], self.kernel_size, self.stride)
         return super().forward(F.pad(x, _as_fpad(pads)))  # zero pad, as the reference
 
+    def forward_valid(self, x):
+        """The same windows, maximum over their VALID elements only (csrc/maxpool3d.hip, mgar_maxpool3d_valid_fwd): what
+        Unit3D.forward_then_pool pools the PRE-BatchNorm tensor with.  Device, NCDHW, forward only."""
+        from .. import _lib as L
+        x = x.contiguous()
+        n, c, t, h, w = x.shape
+        (kt, kh, kw), (st, sh, sw) = self.kernel_size, self.stride
+        y = torch.empty((n, c, -(-t // st), -(-h // sh), -(-w // sw)), dtype=x.dtype, device=x.device)
+        L.payload_call("mgar_maxpool3d_valid_fwd", x.dtype, L.pptr(x, x.dtype), n * c, t, h, w, kt, kh, kw, st, sh, sw,
+                       L.pptr(y, x.dtype), L.stream_of(x))
+        return y
+
 
 class Unit3D(nn.Module):
     """Conv3d (no bias by default) + BatchNorm3d(eps=1e-3, momentum=0.01) + ReLU with dynamic
@@ -112,18 +124,55 @@ class Unit3D(nn.Module):
                        L.stream_of(x))
         return y
 
+    def _conv(self, x):
+        pads = _same_pads(x.shape[2:], self._kernel_shape, self._stride)
+        stem = self._stem_conv(x)
+        if stem is not None:
+            return stem
+        if all(f == b for f, b in pads):
+            return F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
+        return self.conv3d(F.pad(x, _as_fpad(pads)))
+
+    pool_first = True      # forward_then_pool: normalise the pooled tensor instead of the full one (frozen device path)
+
+    def _gamma_positive(self):
+        """gamma > 0 in every channel (what makes relu(bn(.)) monotone non-decreasing); one host read per weight version --
+        the frozen I3D's weights never change, and the first call happens in an eager warm-up step, never inside a capture."""
+        w = self.bn.weight
+        key = (w.data_ptr(), w._version)
+        if getattr(self, "_gamma_pos_key", None) != key:
+            self._gamma_pos_key, self._gamma_pos = key, bool((w.detach() > 0).all().item())
+        return self._gamma_pos
+
+    def forward_then_pool(self, x, pool):
+        """pool(self(x)) for a MaxPool3dSamePadding ``pool`` that directly follows this unit (reference model/backbone.py:305-313:
+        Conv3d_1a_7x7 -> MaxPool3d_2a_3x3, Conv3d_2c_3x3 -> MaxPool3d_3a_3x3), or None where that does not apply.
+        relu(bn(.)) is monotone non-decreasing per channel when gamma > 0 (in fp32 as well) and >= 0, so
+        maxpool_same(relu(bn(z))) == relu(bn(maxpool_valid(z))) bit for bit: the batch statistics come from the FULL
+        pre-BatchNorm tensor z as before, but the normalisation + ReLU pass runs over the pooled tensor (a quarter of z for the
+        stem) -- one read + one write of z less (7.6 GB of the stem's output per c3 step)."""
+        if not (self.pool_first and self._use_batch_norm and self._activation_fn is F.relu and self.bn.training and self.bn.affine
+                and x.is_cuda and x.dim() == 5 and not self.emit_channels_last
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.bn.weight.requires_grad))):
+            return None
+        if torch.cuda.is_current_stream_capturing() and getattr(self, "_gamma_pos_key", None) is None:
+            return None
+        if not self._gamma_positive():
+            return None
+        from .. import bn_ops
+        z = self._conv(x)
+        if z.dtype not in (torch.float32, torch.bfloat16) or not z.is_contiguous():
+            return None
+        stats = bn_ops.bn_train_stats_only(z, self.bn, per_sample=self.per_sample_stats and z.shape[0] > 1)
+        if stats is None:
+            return None
+        return bn_ops.bn_apply_with_stats(pool.forward_valid(z), self.bn, True, stats, per_sample=self.per_sample_stats and z.shape[0] > 1)
+
     def forward(self, x, out=None):
         """``out`` (optional): a channel slice y[:, c0:c1] of a wider tensor the result should land in (the caller's
         concatenation); honoured where the fused BatchNorm + ReLU kernel writes the result, ignored otherwise --
         the caller checks ``result is out``."""
-        pads = _same_pads(x.shape[2:], self._kernel_shape, self._stride)
-        stem = self._stem_conv(x)
-        if stem is not None:
-            x = stem
-        elif all(f == b for f, b in pads):
-            x = F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
-        else:
-            x = self.conv3d(F.pad(x, _as_fpad(pads)))
+        x = self._conv(x)
         relu_fused = False
         if self._use_batch_norm:
             y = None
@@ -269,9 +318,19 @@ class InceptionI3d(nn.Module):
         return self
 
     def extract_features(self, x):
-        for end_point in self.VALID_ENDPOINTS:
-            if end_point in self.end_points:
-                x = self._modules[end_point](x)
+        names = [e for e in self.VALID_ENDPOINTS if e in self.end_points]
+        i = 0
+        while i < len(names):
+            layer = self._modules[names[i]]
+            nxt = self._modules[names[i + 1]] if i + 1 < len(names) else None
+            if isinstance(layer, Unit3D) and isinstance(nxt, MaxPool3dSamePadding):
+                y = layer.forward_then_pool(x, nxt)          # BatchNorm + ReLU after the pooling (same values): device, frozen
+                if y is not None:
+                    x = y
+                    i += 2
+                    continue
+            x = layer(x)
+            i += 1
         return x
 
     def forward(self, x):

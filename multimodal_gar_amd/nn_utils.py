@@ -91,7 +91,7 @@ class PointwiseSequential(nn.Sequential):
         while i < n:
             layer = layers[i]
             # only the layer that consumes the input can hand its gradient back row-major
-            rm = rowmajor_input_grad and i == start and x.dim() == 4 and x.shape[0] == 1
+            rm = rowmajor_input_grad and i == start and x.dim() == 4
             if _is_pointwise(layer):
                 # a conv with no BatchNorm in front (the module's first layer): the streaming kernel also leaves the statistics
                 # partials of its output for the BatchNorm that follows

@@ -32,6 +32,8 @@ def pool_over_samples(x: torch.Tensor, method: str) -> torch.Tensor:
 
 
 class _PointnetSAModuleBase(nn.Module):
+    rowmajor_grad = True    # folded scales: grouping backward without LDS / global float atomics (False: round-2 path, A/B)
+
     def __init__(self):
         super().__init__()
         self.npoint = None
@@ -76,9 +78,12 @@ class _PointnetSAModuleBase(nn.Module):
             pre_idx = self.ball_indices(xyz, new_xyz, n_feat)
         for k, (grouper, mlp) in enumerate(zip(self.groupers, self.mlps)):
             if k in fold:
-                # "project, then group": layer 0 is linear, apply its feature half to the N points first
-                y0 = grouper.forward_projected(xyz, new_xyz, features, mlp[0].weight, idx=pre_idx.get(k))
-                per_scale.append(mlp.forward_maxpool(y0, start=1))
+                # "project, then group": layer 0 is linear, apply its feature half to the N points first.  rows: the grouping
+                # backward on the atomic-free rows kernels (needs the MLP to go on after its first BatchNorm + ReLU -- else that
+                # BatchNorm is fused with the max-pool and its backward is channel-major -- with at most 64 channels)
+                rows = self.rowmajor_grad and len(mlp) > 3 and mlp[0].out_channels <= 64 and torch.is_grad_enabled()
+                y0 = grouper.forward_projected(xyz, new_xyz, features, mlp[0].weight, idx=pre_idx.get(k), rows_bwd=rows)
+                per_scale.append(mlp.forward_maxpool(y0, start=1, rowmajor_input_grad=rows))
                 continue
             grouped = grouper(xyz, new_xyz, features, idx=pre_idx[k]) if k in pre_idx else grouper(xyz, new_xyz, features)   # (B, C', npoint, nsample)
             if self.pool_method == 'max_pool':

@@ -300,31 +300,56 @@ class _FusedQueryGroupProj(Function):
     a first shared-MLP layer whose feature half (zf = W_f features) was applied before grouping."""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, zf, wx, idx):
+    def forward(ctx, xyz, new_xyz, zf, wx, idx, rows_bwd=False):
+        """rows_bwd: the consumer hands the gradient back as rows (nn_utils.forward_maxpool(rowmajor_input_grad=True)); the
+        backward then takes the atomic-free owner-computes kernels of the stacked layout (a dense batch IS a stacked batch with
+        equal counts), which also form d wx from the coordinates -- no relative coordinates are stored for it."""
         batch, n_pts, _ = xyz.size()
         npoint, nsample = idx.size(1), idx.size(2)
         chans = zf.size(1)
         zf, wx = zf.contiguous(), wx.contiguous().float()
+        rows = bool(rows_bwd) and xyz.is_cuda and chans <= 64 and zf.dtype == torch.float32 and n_pts <= 262144 \
+            and batch * npoint * nsample < 2 ** 31
         # rel (relative coordinates) is only read by the backward (d wx): a forward-only call does not write it
-        rel = _new(xyz, (batch, 3, npoint, nsample), zf.dtype) if any(ctx.needs_input_grad) else None
+        rel = _new(xyz, (batch, 3, npoint, nsample), zf.dtype) if any(ctx.needs_input_grad) and not rows else None
         y = _new(xyz, (batch, chans, npoint, nsample), zf.dtype)
         pointnet2.query_group_proj_wrapper(batch, chans, n_pts, npoint, nsample, xyz, new_xyz, zf, wx, idx, rel, y)
-        ctx.save_for_backward(idx, rel)
+        if rows:
+            ctx.save_for_backward(idx, xyz, new_xyz)
+        else:
+            ctx.save_for_backward(idx, rel)
+        ctx.rows = rows
         ctx.dims = (chans, n_pts)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_y):
-        idx, rel = ctx.saved_tensors
         chans, n_pts = ctx.dims
         batch, _, npoint, nsample = grad_y.size()
+        if ctx.rows:
+            # round 3: the LDS-atomic row accumulation of csrc/query_group.hip (qg_batch_bwd_lds_kernel) ran at the pace of the
+            # LDS float-atomic unit (4.3 ms per c3 step); the stacked layout's inverted index + owner-computes rows kernel has no
+            # atomics, a fixed summation order, and reads the gradient as rows -- which is how the MLP's first BatchNorm
+            # backward hands it over (bn_ops._bwd_rowmajor): no transposing copy
+            from ..pointnet2_stack import pointnet2_stack_cuda as S
+            idx, xyz, new_xyz = ctx.saved_tensors
+            cols = batch * npoint * nsample
+            gy_t = grad_y.permute(0, 2, 3, 1)                                   # (B, M, ns, C): contiguous iff the memory is rows
+            gy_t = (gy_t if gy_t.is_contiguous() else gy_t.contiguous()).view(cols, chans)
+            grad_rows = torch.zeros((batch * n_pts, chans), dtype=torch.float32, device=grad_y.device)
+            qcnt = torch.full((batch,), npoint, dtype=torch.int32, device=grad_y.device)
+            pcnt = torch.full((batch,), n_pts, dtype=torch.int32, device=grad_y.device)
+            grad_wx = S.query_group_proj_grad_rows_wrapper(batch, batch * npoint, chans, nsample, gy_t, idx.view(-1, nsample), qcnt, pcnt,
+                                                           grad_rows, xyz=xyz.view(-1, 3), new_xyz=new_xyz.view(-1, 3))
+            return None, None, grad_rows.view(batch, n_pts, chans).transpose(1, 2), grad_wx, None, None
+        idx, rel = ctx.saved_tensors
         grad_y = grad_y.contiguous()
         grad_zf = _new(grad_y, (batch, chans, n_pts), torch.float32, 0.0)
         pointnet2.query_group_proj_grad_wrapper(batch, chans, n_pts, npoint, nsample, grad_y, idx, grad_zf)
         from .....nn_utils import pointwise_dw
         grad_wx = pointwise_dw(rel.flatten(2), grad_y.flatten(2))                              # (C, 3)
-        return None, None, grad_zf, grad_wx, None
+        return None, None, grad_zf, grad_wx, None, None
 
 
 class QueryAndGroup(nn.Module):
@@ -345,7 +370,7 @@ class QueryAndGroup(nn.Module):
             return grouping_operation(features, idx)
         return _FusedQueryGroup.apply(xyz, new_xyz, features, idx)
 
-    def forward_projected(self, xyz, new_xyz, features, weight, idx=None):
+    def forward_projected(self, xyz, new_xyz, features, weight, idx=None, rows_bwd=False):
         """First shared-MLP layer folded into the grouping: returns  W [rel_xyz ; grouped features]
         (B, C_out, npoint, nsample) for a bias-free point-wise conv weight (C_out, 3 + C), without
         ever building the (3 + C)-channel grouped tensor."""
@@ -354,7 +379,7 @@ class QueryAndGroup(nn.Module):
         zf = torch.bmm(w[:, 3:].unsqueeze(0).expand(features.shape[0], -1, -1), features)     # (B, C_out, N)
         if idx is None:
             idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
-        return _FusedQueryGroupProj.apply(xyz, new_xyz, zf, w[:, :3], idx)
+        return _FusedQueryGroupProj.apply(xyz, new_xyz, zf, w[:, :3], idx, rows_bwd)
 
 
 class GroupAll(nn.Module):

@@ -5,6 +5,7 @@
   (oracle/train_objective.py, CPU), values and gradients;
 * NLBlockND ON THE DEVICE vs tests/golden/reference_torch_blocks.npz (outputs of the reference's own class), eval + train.
 """
+import copy
 import os
 import sys
 
@@ -134,3 +135,33 @@ def test_nlblock_on_device_matches_reference(tag, cin, cint, dim):
         got = m(x).detach().cpu().numpy()
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max(), (tag, mode, np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("shape,kernel,stride,cin,cout,per_sample", [((2, 3, 9, 40, 64), (7, 7, 7), (2, 2, 2), 3, 64, True),
+                                                                      ((3, 16, 5, 30, 44), (3, 3, 3), (1, 1, 1), 16, 24, False),
+                                                                      ((1, 8, 4, 17, 23), (1, 1, 1), (1, 1, 1), 8, 12, False)])
+@pytest.mark.parametrize("pool_k,pool_s", [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))])
+def test_unit3d_pooled_first_batchnorm_is_bit_identical(shape, kernel, stride, cin, cout, per_sample, pool_k, pool_s):
+    """Unit3D.forward_then_pool (round 3): BatchNorm + ReLU applied AFTER the max-pool of the pre-BN tensor must equal
+    MaxPool3dSamePadding(Unit3D(x)) bit for bit (monotone per channel for gamma > 0; relu >= 0 absorbs the zero padding), with the
+    same running statistics; a negative gamma falls back (returns None)."""
+    from multimodal_gar_amd.model.backbone import MaxPool3dSamePadding, Unit3D
+    torch.manual_seed(sum(shape))
+    unit = Unit3D(cin, cout, kernel_shape=kernel, stride=stride).to(DEV).train()
+    unit.per_sample_stats = per_sample
+    with torch.no_grad():
+        unit.bn.weight.copy_(torch.rand(cout, device=DEV) + 0.2)
+        unit.bn.bias.copy_(torch.randn(cout, device=DEV) * 0.5)
+    pool = MaxPool3dSamePadding(kernel_size=pool_k, stride=pool_s, padding=0)
+    x = torch.randn(*shape, device=DEV)
+    ref_unit = copy.deepcopy(unit)
+    with torch.no_grad():
+        want = pool(ref_unit(x))
+        got = unit.forward_then_pool(x, pool)
+    assert got is not None and got.shape == want.shape
+    assert torch.equal(got, want)
+    assert torch.equal(unit.bn.running_mean, ref_unit.bn.running_mean) and torch.equal(unit.bn.running_var, ref_unit.bn.running_var)
+    assert int(unit.bn.num_batches_tracked) == int(ref_unit.bn.num_batches_tracked)
+    with torch.no_grad():
+        unit.bn.weight[0] = -0.3                      # relu(bn(.)) decreasing in channel 0: the shortcut must not be taken
+        assert unit.forward_then_pool(x, pool) is None
