@@ -323,7 +323,8 @@ class InceptionI3d(nn.Module):
         while i < len(names):
             layer = self._modules[names[i]]
             nxt = self._modules[names[i + 1]] if i + 1 < len(names) else None
-            if isinstance(layer, Unit3D) and isinstance(nxt, MaxPool3dSamePadding):
+            # (a forward hook on either module wants that module's own output: take the plain path then)
+            if isinstance(layer, Unit3D) and isinstance(nxt, MaxPool3dSamePadding) and not (layer._forward_hooks or nxt._forward_hooks):
                 y = layer.forward_then_pool(x, nxt)          # BatchNorm + ReLU after the pooling (same values): device, frozen
                 if y is not None:
                     x = y

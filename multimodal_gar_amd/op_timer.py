@@ -120,6 +120,10 @@ KERNEL_SOURCES = {
     "three_interp_bwd": "interpolate.hip", "query_group_fwd": "query_group.hip", "query_group_bwd": "query_group.hip",
     "voxel_roi_pool_fwd": "voxel_roi_pool.hip", "voxel_roi_pool_bwd": "voxel_roi_pool.hip", "stem_conv3d_kernel": "stem_conv.hip",
     "query_group_inverse_index": "query_group.hip", "image_resize_normalize": "input_prep.hip",
+    "ball_query_grid_kernel": "ball_query_grid.hip", "three_nn_grid_kernel": "ball_query_grid.hip", "point_grid_build": "ball_query_grid.hip",
+    "spconv_gemm": "sparse_conv.hip", "spconv_dw": "sparse_conv.hip", "spconv_index": "sparse_conv.hip", "gatv2_fwd": "gatv2.hip",
+    "gatv2_bwd": "gatv2.hip", "dafm_attn_fwd": "dafm.hip", "dafm_attn_bwd": "dafm.hip", "roi_align_fwd": "roi_align.hip",
+    "roi_align_bwd": "roi_align.hip", "voxel_query_kernel": "voxel_query.hip",
 }
 
 
