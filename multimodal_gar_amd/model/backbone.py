@@ -162,17 +162,22 @@ class Unit3D(nn.Module):
         from .. import bn_ops
         z = self._conv(x)
         if z.dtype not in (torch.float32, torch.bfloat16) or not z.is_contiguous():
-            return None
+            return pool(self._bn_relu(z))
+        per = z.shape[2] * z.shape[3] * z.shape[4] * (1 if (self.per_sample_stats and z.shape[0] > 1) else z.shape[0])
+        if per <= bn_ops.SMALL_CHANNEL_MAX:      # small tensors: the one-launch statistics + apply kernel of the plain path (nothing to gain here,
+            return pool(self._bn_relu(z))        # and its statistics arithmetic differs in the last bits)
         stats = bn_ops.bn_train_stats_only(z, self.bn, per_sample=self.per_sample_stats and z.shape[0] > 1)
         if stats is None:
-            return None
+            return pool(self._bn_relu(z))
         return bn_ops.bn_apply_with_stats(pool.forward_valid(z), self.bn, True, stats, per_sample=self.per_sample_stats and z.shape[0] > 1)
 
     def forward(self, x, out=None):
         """``out`` (optional): a channel slice y[:, c0:c1] of a wider tensor the result should land in (the caller's
         concatenation); honoured where the fused BatchNorm + ReLU kernel writes the result, ignored otherwise --
         the caller checks ``result is out``."""
-        x = self._conv(x)
+        return self._bn_relu(self._conv(x), out)
+
+    def _bn_relu(self, x, out=None):
         relu_fused = False
         if self._use_batch_norm:
             y = None

@@ -137,8 +137,9 @@ def test_nlblock_on_device_matches_reference(tag, cin, cint, dim):
         assert np.abs(got - want).max() <= 1e-6 + 1e-4 * np.abs(want).max(), (tag, mode, np.abs(got - want).max())
 
 
-@pytest.mark.parametrize("shape,kernel,stride,cin,cout,per_sample", [((2, 3, 9, 40, 64), (7, 7, 7), (2, 2, 2), 3, 64, True),
+@pytest.mark.parametrize("shape,kernel,stride,cin,cout,per_sample", [((2, 3, 9, 96, 160), (7, 7, 7), (2, 2, 2), 3, 64, True),
                                                                       ((3, 16, 5, 30, 44), (3, 3, 3), (1, 1, 1), 16, 24, False),
+                                                                      ((2, 8, 6, 60, 64), (1, 1, 1), (1, 1, 1), 8, 12, False),
                                                                       ((1, 8, 4, 17, 23), (1, 1, 1), (1, 1, 1), 8, 12, False)])
 @pytest.mark.parametrize("pool_k,pool_s", [((1, 3, 3), (1, 2, 2)), ((3, 3, 3), (2, 2, 2))])
 def test_unit3d_pooled_first_batchnorm_is_bit_identical(shape, kernel, stride, cin, cout, per_sample, pool_k, pool_s):
