@@ -87,6 +87,10 @@ def parse():
     ap.add_argument("--ddp-wrapper", action="store_true",
                     help="eager DistributedDataParallel (bucketed all-reduce overlapped with backward) instead of one flattened "
                          "gradient all-reduce after the backward; implies --no-graph (DDP hooks cannot be captured)")
+    ap.add_argument("--prefetch-geometry", action="store_true",
+                    help="input-side software pipelining (off by default): every step computes the PointNet++ trunk's coordinate-only "
+                         "work (FPS, ball queries, 3-NN weights) for the NEXT batch on a side stream while it runs the feature path and "
+                         "the backward of the current one; the same work per step, the level-1 FPS off the critical path")
     ap.add_argument("--phases", action="store_true", help="print a synchronised per-phase timing of one step")
     ap.add_argument("--kernels-out", default=None,
                     help="where the per-kernel roofline table of the instrumented step is written (default: "
@@ -459,6 +463,7 @@ def main():
         # the host the two-stream step measured 362 ms against 269 ms on one stream (and 257 ms as a graph on two).
         step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
         step.module.i3d_channels_last = bool(args.i3d_channels_last)
+        step.module.geometry_prefetch = bool(args.prefetch_geometry) and args.mode == "train"
         batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
         log("model + batch ready; %.1f GB allocated" % (torch.cuda.memory_allocated() / 2 ** 30))
         if args.phases and rank == 0 and not ddp:
@@ -533,6 +538,7 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": workload, "global_clips": args.clips, "clips_per_gpu": clips_local, "parallelism": "dp%d" % world,
                        "launch": "hip_graph" if step.graph is not None else "eager",
+                       "geometry": "prefetched one step ahead (input pipelining)" if args.prefetch_geometry else "in step",
                        "gradient_exchange": "none" if world == 1 else ("ddp_bucketed" if args.ddp_wrapper else "flat_allreduce"),
                        "trainable_params": W.trainable_parameter_count(step.module)},
             "roofline": roof, "cpu_baseline": cpu, "step_accounting": accounting,

@@ -141,6 +141,15 @@ class ClipModel(nn.Module):
         # stream.  "all" measured SLOWER inside the HIP graph (1 clip: 45.4 vs 42.3 ms; c3: 244.2 vs 235.2 ms/step,
         # profiles/README.md round 2): the extra branch delays the feature path's kernels more than it hides.
         self.geometry_ahead = "fps1"
+        # Opt-in (bench.py --prefetch-geometry): input-side software pipelining.  The trunk's coordinate-only work (FPS of all
+        # levels, ball queries, 3-NN weights) depends on the points alone, so a step can compute it for the NEXT batch on a side
+        # stream while it runs the feature path and the backward of the current one -- as a loader would.  Every step still does
+        # the geometry of one batch and the forward + backward of one batch; only the order changes.  It takes the level-1 FPS
+        # (4.6 ms on 15 workgroups at one clip per rank) off the critical path.  Off by default: the headline numbers are the
+        # un-pipelined step.
+        self.geometry_prefetch = False
+        self._geo_cur = None        # geometry of the batch this step consumes (computed during the previous step)
+        self._geo_next = None       # geometry being computed for the next step (owned by the side stream until finish_prefetch)
 
     # ---- RGB: one I3D pass per clip (batch 1, like the reference) ---------------------------------
     def rgb_crops(self, images, bboxes):
@@ -214,6 +223,23 @@ class ClipModel(nn.Module):
         tok = lb(data)                                           # (1, F*A, 512)
         return tok.view(f, a, -1)
 
+    def finish_prefetch(self):
+        """After the step's BACKWARD (its saved index tensors are the current geometry): join the side stream that computed
+        the next batch's geometry and make it the current one -- by copying into the current buffers, so that a captured HIP
+        graph keeps reading the same addresses."""
+        if self._geo_next is None:
+            return
+        main = torch.cuda.current_stream()
+        main.wait_stream(self._geo_stream)
+        src, dst = _geometry_tensors(self._geo_next), _geometry_tensors(self._geo_cur)
+        assert len(src) == len(dst)
+        capturing = torch.cuda.is_current_stream_capturing()
+        for a_, b_ in zip(dst, src):
+            if not capturing:
+                b_.record_stream(main)
+            a_.copy_(b_)
+        self._geo_next = None
+
     def forward(self, batch):
         b, t, a = batch["n_clips"], batch["n_frames"], self.n_actors
         if batch["images"].is_cuda and self.overlap_branches:
@@ -226,13 +252,23 @@ class ClipModel(nn.Module):
                 self._side_stream, self._geo_stream = torch.cuda.Stream(), torch.cuda.Stream()
             inputs_ready = main.record_event()
             self._geo_stream.wait_event(inputs_ready)
-            geometry = self.trunk_geometry(batch["points"], self._geo_stream if self.geometry_ahead == "all" else main)   # FPS first
+            prefetch = self.geometry_prefetch and self.route == "pointnet2"
+            if prefetch:
+                trunk = self.net.LiDAR_backbone.model.backbone_3d
+                if self._geo_cur is None:      # first step: nothing was prefetched -- compute it in line, once
+                    self._geo_cur = _without_events(trunk.geometry(batch["points"]))
+                geometry = self._geo_cur
+                # the NEXT batch's geometry (the caller passes its points; the benchmark's batches are all the same tensor)
+                self._geo_next = trunk.geometry(batch.get("next_points", batch["points"]), self._geo_stream)
+            else:
+                geometry = self.trunk_geometry(batch["points"], self._geo_stream if self.geometry_ahead == "all" else main)   # FPS first
             self._side_stream.wait_event(inputs_ready)
             with torch.cuda.stream(self._side_stream):
                 crops = self.rgb_crops(batch["images"], batch["bboxes"])
             lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], geometry)   # (B*T, A, 512)
             main.wait_stream(self._side_stream)
-            main.wait_stream(self._geo_stream)
+            if not prefetch:
+                main.wait_stream(self._geo_stream)
             if not torch.cuda.is_current_stream_capturing():   # inside a graph the pool is private and replays are serial
                 for c in crops:
                     c.record_stream(main)
@@ -247,6 +283,26 @@ class ClipModel(nn.Module):
         # configuration (under the bf16 configurations the token producers above are bf16; the tokens are widened here).
         with torch.autocast(device_type=rgb_s.device.type, enabled=False):
             return self.net.GAR_model(pad(rgb_s.float()), pad(lidar.float()), bb2, batch["bboxes3d"], None, batch["person_id"])
+
+
+def _geometry_tensors(geo):
+    out = list(geo.centres)
+    for idx in geo.ball_idx:
+        if isinstance(idx, dict):
+            out += [idx[k] for k in sorted(idx)]
+        elif torch.is_tensor(idx):
+            out.append(idx)
+    for i in sorted(geo.nn):
+        out += list(geo.nn[i])
+    return out
+
+
+def _without_events(geo):
+    """The same TrunkGeometry with no stream events: its producer has been joined already (or ran on the consumer's stream)."""
+    geo.centre_events = [None] * len(geo.centre_events)
+    geo.idx_events = [None] * len(geo.idx_events)
+    geo.nn_events = {i: None for i in geo.nn_events}
+    return geo
 
 
 def voxelize_batch(points, dataset, max_points=5, max_voxels=40000):
@@ -332,6 +388,7 @@ class TrainStep:
             (loss * dist.get_world_size()).backward()
         else:
             loss.backward()
+        self.module.finish_prefetch()
         return loss.detach()
 
     def _loss_of(self, out, batch):
@@ -397,6 +454,7 @@ class TrainStep:
             out = self.model(batch)
             loss = self._loss_of(out, batch)
             loss.backward()
+            self.module.finish_prefetch()
         self.graph, self._loss = graph, loss.detach()
         self._graph_grads = [p.grad for p in self.params]   # the buffers every replay writes (graph-private pool)
         return self

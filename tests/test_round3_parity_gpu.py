@@ -166,3 +166,46 @@ def test_unit3d_pooled_first_batchnorm_is_bit_identical(shape, kernel, stride, c
     with torch.no_grad():
         unit.bn.weight[0] = -0.3                      # relu(bn(.)) decreasing in channel 0: the shortcut must not be taken
         assert unit.forward_then_pool(x, pool) is None
+
+
+def test_geometry_prefetch_gives_the_same_step():
+    """ClipModel.geometry_prefetch (bench.py --prefetch-geometry): the trunk's coordinate-only work computed one step ahead on a side
+    stream must hand the feature path exactly what the in-step computation does: same loss, same gradients (eager and from a
+    captured HIP graph), for a batch that stays the same and for one that CHANGES between steps (next_points)."""
+    from multimodal_gar_amd import workload as W
+
+    def build(prefetch):
+        step = W.TrainStep(4, 2048, DEV, seed=11, manual_allreduce=True)
+        for m in step.module.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+                m.dropout = 0.0
+        step.module.geometry_prefetch = prefetch
+        return step
+    b1 = W.make_batch(3, 1, 2, 4, 2048, 96, 160, DEV)
+    b2 = W.make_batch(4, 1, 2, 4, 2048, 96, 160, DEV)
+    plain, pre = build(False), build(True)
+    pre.module.load_state_dict(plain.module.state_dict())
+
+    def grads(step):
+        return {n: p.grad.detach().clone() for n, p in step.module.named_parameters() if p.grad is not None}
+    # step 1 on b1 (prefetching b2's geometry), step 2 on b2: the second step of the prefetching model consumes prefetched geometry
+    l1 = plain._forward_backward(b1); g1 = grads(plain)
+    l2 = plain._forward_backward(b2); g2 = grads(plain)
+    p1 = pre._forward_backward(dict(b1, next_points=b2["points"])); q1 = grads(pre)
+    p2 = pre._forward_backward(dict(b2, next_points=b2["points"])); q2 = grads(pre)
+    torch.cuda.synchronize()
+    for la, lb, ga, gb in ((l1, p1, g1, q1), (l2, p2, g2, q2)):
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)) + 1e-7
+        assert set(ga) == set(gb) and len(ga) > 100
+        worst = max(((ga[n] - gb[n]).abs().max().item() / (ga[n].abs().max().item() + 1e-12)) for n in ga)
+        assert worst < 1e-4, worst          # run-to-run noise of the float-atomic kernels only
+    # and from a captured graph on a static batch
+    g = build(True)
+    g.module.load_state_dict(plain.module.state_dict())
+    g.capture(b2, warmup=2)
+    g.module.load_state_dict(plain.module.state_dict())
+    g.graph.replay(); g.graph.replay()
+    torch.cuda.synchronize()
+    assert abs(float(g._loss) - float(l2)) <= 1e-4 * abs(float(l2)) + 1e-6
