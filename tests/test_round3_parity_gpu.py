@@ -209,3 +209,50 @@ def test_geometry_prefetch_gives_the_same_step():
     g.graph.replay(); g.graph.replay()
     torch.cuda.synchronize()
     assert abs(float(g._loss) - float(l2)) <= 1e-4 * abs(float(l2)) + 1e-6
+
+
+def test_c2_full_size_integer_outputs_vs_c_oracle(oracle):
+    """at config c2's full per-frame size (16 actors, 8 192 points; two frames of each of its 4 clips) every
+    integer output of the LiDAR path -- FPS indices of the four levels, the ball-query rows of both radii per level, the 3-NN
+    indices of the four decoder levels, the RoI-grid ball queries of the three radii -- against the C oracle itself (round 2
+    compared the bf16 run with the fp32 DEVICE run at this size).  Geometry is fp32 / int32 whatever the payload type, so
+    these are the tensors the bf16 configuration uses."""
+    from multimodal_gar_amd import synthetic as S, workload as W
+    from multimodal_gar_amd.pcdet.models.roi_heads.voxelrcnn_head import global_grid_points_of_roi
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_batch import pointnet2_utils as pb
+    from multimodal_gar_amd.pcdet.ops.pointnet2.pointnet2_stack import pointnet2_utils as ps
+    f, a, p = 8, 16, 8192
+    sc = S.scene_batch(202, f, a, p)
+    cfg = W.lidar_model_cfg(p)
+    sa = cfg.BACKBONE_3D.SA_CONFIG
+    xyz = np.ascontiguousarray(sc["points"][:, :, :3])
+    levels = [xyz]
+    for k, m in enumerate(sa.NPOINTS):
+        cur = levels[-1]
+        t = torch.from_numpy(cur).to(DEV)
+        got = pb.farthest_point_sample(t, m).cpu().numpy()
+        want, _ = oracle.fps_batch(cur, m)
+        assert np.array_equal(got, want), "FPS level %d" % (k + 1)
+        centres = np.stack([cur[b][want[b]] for b in range(f)])
+        ct = torch.from_numpy(centres).to(DEV)
+        multi = pb.ball_query_multi(list(sa.RADIUS[k]), list(sa.NSAMPLE[k]), t, ct)
+        for r, ns, idx in zip(sa.RADIUS[k], sa.NSAMPLE[k], multi):
+            assert np.array_equal(idx.cpu().numpy(), oracle.ball_query_batch(r, ns, cur, centres)), "ball query level %d r %g" % (k + 1, r)
+        levels.append(centres)
+    for k in range(len(levels) - 1):          # decoder: unknown = level k, known = level k + 1
+        d, i = pb.three_nn(torch.from_numpy(levels[k]).to(DEV), torch.from_numpy(levels[k + 1]).to(DEV))
+        want_d, want_i = oracle.three_nn_batch(levels[k], levels[k + 1])
+        assert np.array_equal(i.cpu().numpy(), want_i), "three_nn level %d" % (k + 1)
+        assert np.array_equal(d.cpu().numpy(), np.sqrt(want_d)) or np.allclose(d.cpu().numpy(), np.sqrt(want_d), rtol=1e-7, atol=0)
+    # RoI-grid lift: 16 actors x 216 grid points per frame against the 8 192 points of the frame, radii of mil3.yaml:105-134
+    grid_xyz, _ = global_grid_points_of_roi(torch.from_numpy(sc["bboxes3d"][:, :a]), cfg.ROI_HEAD.ROI_GRID_POOL.GRID_SIZE)
+    q = np.ascontiguousarray(grid_xyz.view(-1, 3).numpy())
+    cnt, qcnt = np.full((f,), p, np.int32), np.full((f,), a * 216, np.int32)
+    sx = np.ascontiguousarray(xyz.reshape(-1, 3))
+    for r, ns in zip(cfg.ROI_HEAD.ROI_GRID_POOL.POOL_RADIUS, cfg.ROI_HEAD.ROI_GRID_POOL.NSAMPLE):
+        idx, empty = ps.ball_query(r, ns, torch.from_numpy(sx).to(DEV), torch.from_numpy(cnt).to(DEV), torch.from_numpy(q).to(DEV),
+                                   torch.from_numpy(qcnt).to(DEV))
+        raw = oracle.ball_query_stack(r, ns, sx, cnt, q, qcnt)
+        want_empty = raw[:, 0] == -1
+        want = raw.copy(); want[want_empty] = 0           # pointnet2_stack/pointnet2_utils.py:36-37
+        assert np.array_equal(empty.cpu().numpy(), want_empty) and np.array_equal(idx.cpu().numpy(), want), "RoI ball query r %g" % r
