@@ -160,6 +160,11 @@ int mgar_three_interpolate_grad_sorted_batch(int b, int c, int n, int m, const f
  * interpolated half of the decoder's torch.cat([interpolated, skip]) is written where the concatenation wants it. */
 int mgar_three_interpolate_batch_into(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
                                       float *out, long long out_bstride, void *stream);
+/* out (b, c, n) += three_interpolate(points, idx, weight): the caller pre-fills out.  "Project, then interpolate": the first layer of
+ * a feature-propagation MLP is linear and so is the interpolation, W [interp(f) ; skip] = interp(W_a f) + W_b skip
+ * (pointnet2_batch/pointnet2_modules.py:139-150) -- the known features are projected on the coarse level first. */
+int mgar_three_interpolate_batch_add(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                     float *out, void *stream);
 /* Both with grad_out a CHANNEL SLICE of a wider (b, c_total, n) tensor: consecutive samples are grad_out_bstride >= c * n
  * elements apart.  The decoder (reference PointnetFPModule, pointnet2_batch/pointnet2_modules.py:139-148) concatenates the
  * interpolated features with the skip features; the gradient of that torch.cat hands this op a slice, which the reference's
@@ -713,6 +718,8 @@ int mgar_bn_act_fwd_bf16(const void *x, int B, int C, int P, const float *mean, 
                          const float *gamma, const float *beta, int relu, void *y, void *stream);
 int mgar_three_interpolate_batch_into_bf16(int b, int c, int m, int n, const void *points, const int *idx, const float *weight,
                                            void *out, long long out_bstride, void *stream);
+int mgar_three_interpolate_batch_add_bf16(int b, int c, int m, int n, const void *points, const int *idx, const float *weight,
+                                          void *out, void *stream);
 int mgar_bn_cl_train_stats_bf16(const void *x, int S, int R, int C, int per_sample, float eps, float momentum, float *workspace,
                                 float *mean, float *invstd, float *running_mean, float *running_var,
                                 long long *num_batches_tracked, void *stream);

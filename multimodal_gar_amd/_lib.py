@@ -43,6 +43,7 @@ _PROTOS = {
     "mgar_fps_batch_buckets_workspace_floats": [_I, _I],
     "mgar_three_nn_batch": [_I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "mgar_three_interpolate_batch_add": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_batch": [_I, _I, _I, _I, _P, _P, _P, _P, _P],
     "mgar_three_interpolate_grad_sorted_batch": [_I, _I, _I, _I, _P, _P, _P, _P],
     "mgar_three_interpolate_batch_into": [_I, _I, _I, _I, _P, _P, _P, _P, _LL, _P],
@@ -149,7 +150,7 @@ for _n in ("mgar_query_group_batch_fwd", "mgar_query_group_stack_fwd", "mgar_que
            "mgar_query_group_proj_stack_fwd", "mgar_bn_train_stats", "mgar_bn_train_stats_grouped", "mgar_bn_act_fwd",
            "mgar_bn_act_fwd_grouped", "mgar_bn_act_fwd_into", "mgar_bn_act_small", "mgar_bn_cl_train_stats", "mgar_bn_cl_act_fwd", "mgar_bn_act_fwd_to_cl",
            "mgar_maxpool3d_same_fwd_cl", "mgar_bn_act_maxpool_fwd", "mgar_bn_act_bwd", "mgar_bn_act_maxpool_bwd",
-           "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_batch_into", "mgar_three_interpolate_stack",
+           "mgar_pointwise_conv_fwd", "mgar_three_interpolate_batch", "mgar_three_interpolate_batch_into", "mgar_three_interpolate_batch_add", "mgar_three_interpolate_stack",
            "mgar_maxpool3d_same_fwd", "mgar_maxpool3d_valid_fwd", "mgar_roi_align_fwd", "mgar_voxel_roi_pool_fwd", "mgar_stem_conv3d_fwd"):
     _PROTOS[_n + "_bf16"] = _PROTOS[_n]
 BF16_TWINS = frozenset(n[:-5] for n in _PROTOS if n.endswith("_bf16"))

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(1024) void three_interp_batch_fwd_lds_kernel(int c,
                                                                           const T *__restrict__ points,
                                                                           const int *__restrict__ idx,
                                                                           const float *__restrict__ weight,
-                                                                          T *__restrict__ out, size_t out_bs) {
+                                                                          T *__restrict__ out, size_t out_bs, int accumulate) {
     extern __shared__ float rows[];  // [CH][m]
     const int c0 = blockIdx.x * CH, bs = blockIdx.y;
     const int nch = min(CH, c - c0);
@@ -135,7 +135,9 @@ __global__ __launch_bounds__(1024) void three_interp_batch_fwd_lds_kernel(int c,
         const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
         for (int ch = 0; ch < nch; ++ch) {
             const float *r = rows + (size_t)ch * m;
-            Payload<T>::st(dst + (size_t)ch * n + pt, dot3_of(w0, r[i0], w1, r[i1], w2, r[i2]));
+            float v = dot3_of(w0, r[i0], w1, r[i1], w2, r[i2]);
+            if (accumulate) v += Payload<T>::ld(dst + (size_t)ch * n + pt);   // out = out + interpolation (see mgar_three_interpolate_batch_add)
+            Payload<T>::st(dst + (size_t)ch * n + pt, v);
         }
     }
 }
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int 
                                                                      const T *__restrict__ points,
                                                                      const int *__restrict__ idx,
                                                                      const float *__restrict__ weight,
-                                                                     T *__restrict__ out, size_t out_bs) {
+                                                                     T *__restrict__ out, size_t out_bs, int accumulate) {
     const int pt = blockIdx.x * 256 + threadIdx.x;
     if (pt >= n) return;
     const int bs = blockIdx.z;
@@ -299,7 +301,9 @@ __global__ __launch_bounds__(256) void three_interp_batch_fwd_kernel(int c, int 
     const T *src = points + ((size_t)bs * c + c0) * m;
     T *dst = out + (size_t)bs * out_bs + (size_t)c0 * n + pt;
     for (int ci = c0; ci < c1; ++ci) {
-        Payload<T>::st(dst, dot3_of(w0, Payload<T>::ld(src + i0), w1, Payload<T>::ld(src + i1), w2, Payload<T>::ld(src + i2)));
+        float v = dot3_of(w0, Payload<T>::ld(src + i0), w1, Payload<T>::ld(src + i1), w2, Payload<T>::ld(src + i2));
+        if (accumulate) v += Payload<T>::ld(dst);
+        Payload<T>::st(dst, v);
         src += m;
         dst += n;
     }
@@ -423,7 +427,7 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_nn_stack(int ba
 
 template <typename T>
 static int three_interpolate_batch_impl(int b, int c, int m, int n, const T *points, const int *idx, const float *weight, T *out,
-                                        void *stream, long long out_bstride = -1) {
+                                        void *stream, long long out_bstride = -1, int accumulate = 0) {
     MGAR_REQUIRE(b >= 0 && c >= 0 && m >= 0 && n >= 0, "three_interpolate_batch: negative size");
     if (out_bstride < 0) out_bstride = (long long)c * n;
     MGAR_REQUIRE(out_bstride >= (long long)c * n, "three_interpolate_batch: output batch stride smaller than a sample");
@@ -444,11 +448,11 @@ static int three_interpolate_batch_impl(int b, int c, int m, int n, const T *poi
         ch = ch > 8 ? 8 : ch;
         while (ch > 1 && (long long)b * ceil_div(c, ch) < 512) ch >>= 1;
         hipLaunchKernelGGL(three_interp_batch_fwd_lds_kernel<T>, dim3(ceil_div(c, ch), b), dim3(n >= 4096 ? 1024 : 256),
-                           (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, m, n, ch, points, idx, weight, out, out_bs);
+                           (size_t)ch * m * sizeof(float), (hipStream_t)stream, c, m, n, ch, points, idx, weight, out, out_bs, accumulate);
     } else {
         dim3 grid(ceil_div(n, 256), ceil_div(c, TI_CCHUNK), b);
         hipLaunchKernelGGL(three_interp_batch_fwd_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, c, m, n, points, idx,
-                           weight, out, out_bs);
+                           weight, out, out_bs, accumulate);
     }
     return check_launch("three_interpolate_batch: launch failed");
 }
@@ -461,6 +465,20 @@ extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_bat
 extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_bf16(int b, int c, int m, int n, const void *points, const int *idx,
                                             const float *weight, void *out, void *stream) {
     return three_interpolate_batch_impl<bf16_t>(b, c, m, n, (const bf16_t *)points, idx, weight, (bf16_t *)out, stream);
+}
+
+// out (b, c, n) += interpolation: the caller pre-fills out.  "Project, then interpolate" (round 3): the first shared-MLP layer of
+// a feature-propagation module is linear and the interpolation is linear per channel, so
+//     W [interp(f) ; skip] = interp(W_a f) + W_b skip
+// -- the known features are projected on the COARSE level (m columns instead of n), the skip term is one GEMM with K = C_skip, and
+// this kernel adds the interpolation of the projected features into it (reference pointnet2_batch/pointnet2_modules.py:139-150).
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_add(int b, int c, int m, int n, const float *points, const int *idx,
+                                            const float *weight, float *out, void *stream) {
+    return three_interpolate_batch_impl<float>(b, c, m, n, points, idx, weight, out, stream, -1, 1);
+}
+extern "C" __attribute__((visibility("default"))) int mgar_three_interpolate_batch_add_bf16(int b, int c, int m, int n, const void *points, const int *idx,
+                                            const float *weight, void *out, void *stream) {
+    return three_interpolate_batch_impl<bf16_t>(b, c, m, n, (const bf16_t *)points, idx, weight, (bf16_t *)out, stream, -1, 1);
 }
 
 // out a CHANNEL SLICE of a wider (b, c_total, n) tensor (samples out_bstride >= c * n elements apart): the decoder's

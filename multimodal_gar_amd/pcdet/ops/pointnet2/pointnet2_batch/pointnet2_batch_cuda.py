@@ -123,6 +123,14 @@ def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
     return 1
 
 
+def three_interpolate_add_wrapper(b, c, m, n, points, idx, weight, out):
+    """out (b, c, n) += three_interpolate(points, idx, weight)  (csrc/interpolate.hip, accumulate flag)."""
+    dt = points.dtype
+    L.payload_call("mgar_three_interpolate_batch_add", dt, b, c, m, n, L.pptr(points, dt), L.iptr(idx), L.fptr(weight), L.pptr(out, dt),
+                   L.stream_of(points))
+    return 1
+
+
 def three_interpolate_into_wrapper(b, c, m, n, points, idx, weight, merged):
     """three_interpolate into the first c channels of merged (b, c_total, n) (contiguous)."""
     dt = points.dtype

@@ -130,6 +130,30 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = shared_mlp_2d(mlp)
 
+    project_first = True    # device path: "project, then interpolate" (False: interpolate, concatenate, convolve -- the reference's order)
+
+    def _project_then_interpolate(self, idx, weight, unknow_feats, known_feats):
+        """The module's forward with its first layer applied BEFORE the interpolation (round 3).  The first shared-MLP layer is
+        a bias-free 1x1 convolution W = [W_a | W_b] over cat([interp(f), skip]) and the three-point interpolation is linear per
+        channel, so  W cat([interp(f), skip]) = interp(W_a f) + W_b skip:  W_a f is a GEMM over the m KNOWN points (a quarter of
+        the n unknown ones at every level of PointNet2MSG), the interpolation moves C_1 <= C_known channels, and the (C_known + C_skip,
+        n) concatenated tensor is never built (2 GB per step at the finest level of config c3).  Same sums in another order.
+        None where it does not apply (CPU, no skip features, a first layer with a bias or wider than the known features)."""
+        from .....nn_utils import _is_pointwise
+        if not (self.project_first and known_feats.is_cuda and unknow_feats is not None and len(self.mlp) and _is_pointwise(self.mlp[0])
+                and self.mlp[0].bias is None and hasattr(pointnet2_utils.pointnet2, "three_interpolate_add_wrapper")):
+            return None
+        conv = self.mlp[0]
+        c_known, c_skip = known_feats.shape[1], unknow_feats.shape[1]
+        if conv.in_channels != c_known + c_skip or conv.out_channels > c_known or known_feats.dtype != unknow_feats.dtype:
+            return None
+        w = conv.weight.view(conv.out_channels, conv.in_channels).to(known_feats.dtype)
+        b = known_feats.shape[0]
+        zf = torch.bmm(w[:, :c_known].unsqueeze(0).expand(b, -1, -1), known_feats)                 # (B, C_1, m)
+        zs = torch.bmm(w[:, c_known:].unsqueeze(0).expand(b, -1, -1), unknow_feats)               # (B, C_1, n)
+        z1 = pointnet2_utils.ThreeInterpolateAdd.apply(zf.contiguous(), idx, weight, zs.contiguous())
+        return self.mlp._run(z1.unsqueeze(-1), False, start=1)[0].squeeze(-1)
+
     @staticmethod
     def neighbour_weights(unknown, known):
         """three_nn + inverse-distance weights (reference pointnet2_modules.py:137-140) -> (idx, weight): pure geometry."""
@@ -142,6 +166,9 @@ class PointnetFPModule(nn.Module):
         """``nn_weights``: neighbour_weights(unknown, known) computed ahead of time by the caller (same values)."""
         if known is not None:
             idx, weight = nn_weights if nn_weights is not None else self.neighbour_weights(unknown, known)
+            y = self._project_then_interpolate(idx, weight, unknow_feats, known_feats)
+            if y is not None:
+                return y
             if unknow_feats is not None and known_feats.is_cuda:
                 # interpolation written straight into the concatenated tensor (no copy of the interpolated half)
                 merged = pointnet2_utils.three_interpolate_concat(known_feats, idx, weight, unknow_feats)

@@ -194,6 +194,31 @@ class ThreeInterpolateConcat(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+class ThreeInterpolateAdd(Function):
+    """base + three_interpolate(features, idx, weight), the interpolation added IN PLACE into ``base`` (a fresh tensor of the
+    caller: the skip projection of PointnetFPModule's "project, then interpolate" path) -- csrc/interpolate.hip,
+    mgar_three_interpolate_batch_add.  Device only."""
+
+    @staticmethod
+    def forward(ctx, features, idx, weight, base):
+        assert features.is_cuda and features.is_contiguous() and idx.is_contiguous() and weight.is_contiguous() and base.is_contiguous()
+        batch, chans, n_known = features.size()
+        n_unknown = idx.size(1)
+        assert base.shape == (batch, chans, n_unknown) and base.dtype == features.dtype
+        pointnet2.three_interpolate_add_wrapper(batch, chans, n_known, n_unknown, features, idx, weight.float(), base)
+        ctx.mark_dirty(base)
+        ctx.save_for_backward(idx, weight)
+        ctx.n_known = n_known
+        return base
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        grad_features = _three_interpolate_backward(grad_out, idx, weight, ctx.n_known) if ctx.needs_input_grad[0] else None
+        return grad_features, None, None, grad_out if ctx.needs_input_grad[3] else None
+
+
 def three_interpolate_concat(features, idx, weight, skip):
     """cat([three_interpolate(features, idx, weight), skip], 1); on the device in one pass over the interpolated half."""
     if features.is_cuda and skip.dtype == features.dtype and hasattr(pointnet2, "three_interpolate_into_wrapper"):
