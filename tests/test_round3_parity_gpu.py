@@ -245,8 +245,8 @@ def test_c2_full_size_integer_outputs_vs_c_oracle(oracle):
         assert np.array_equal(i.cpu().numpy(), want_i), "three_nn level %d" % (k + 1)
         assert np.array_equal(d.cpu().numpy(), np.sqrt(want_d)) or np.allclose(d.cpu().numpy(), np.sqrt(want_d), rtol=1e-7, atol=0)
     # RoI-grid lift: 16 actors x 216 grid points per frame against the 8 192 points of the frame, radii of mil3.yaml:105-134
-    grid_xyz, _ = global_grid_points_of_roi(torch.from_numpy(sc["bboxes3d"][:, :a]), cfg.ROI_HEAD.ROI_GRID_POOL.GRID_SIZE)
-    q = np.ascontiguousarray(grid_xyz.view(-1, 3).numpy())
+    grid_xyz, _ = global_grid_points_of_roi(torch.from_numpy(np.ascontiguousarray(sc["bboxes3d"][:, :a])), cfg.ROI_HEAD.ROI_GRID_POOL.GRID_SIZE)
+    q = np.ascontiguousarray(grid_xyz.reshape(-1, 3).numpy())
     cnt, qcnt = np.full((f,), p, np.int32), np.full((f,), a * 216, np.int32)
     sx = np.ascontiguousarray(xyz.reshape(-1, 3))
     for r, ns in zip(cfg.ROI_HEAD.ROI_GRID_POOL.POOL_RADIUS, cfg.ROI_HEAD.ROI_GRID_POOL.NSAMPLE):
