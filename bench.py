@@ -110,7 +110,7 @@ def parse():
 # single stream, so that every kernel has the chip to itself between its two events -- and the headline number
 # is not perturbed by ~3 000 event records per step.
 # --------------------------------------------------------------------------------------------
-MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel", "stem_conv3d_kernel", "spconv_gemm", "spconv_dw")
+MFMA_KERNELS = ("pointwise_fwd_kernel", "pointwise_dw_kernel", "rowmajor_dw_kernel", "stem_conv3d_kernel", "spconv_gemm", "spconv_dw", "conv3d_wino_kernel")
 PAIR_KERNELS = ("fps_kernel", "ball_query_kernel", "three_nn_kernel")   # (query, point) scans: VALU-bound, pair evaluations of 8 flop
 PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")   # rocprofv3 --pmc passes, see profiles/README.md
 

@@ -493,6 +493,16 @@ int mgar_stem_conv3d_workspace_floats(void);
 int mgar_stem_conv3d_fwd(const float *x, int N, int T, int H, int W, const float *w, float *w_packed, float *y,
                          void *stream);
 
+/* The 3x3x3, stride-1, "same"-padded convolutions of Inception-I3D (model/backbone.py:311-312 ``Conv3d_2c_3x3`` and the
+ * ``Conv3d_0b_3x3`` units of every InceptionModule :215-236; Unit3D :134-206 = pad + nn.Conv3d(bias=False)) on the fp32 MFMA
+ * with the Winograd F(2, 3) identity along W (2/3 of the direct convolution's multiply-accumulates), NCDHW in and out,
+ * padding handled in the kernel.  x (N, Cin, D, H, W), w (Cout, Cin, 3, 3, 3) -> y (N, Cout, D, H, W).  Cin and W must be
+ * even.  w_packed: caller-allocated scratch of mgar_conv3d_k3_workspace_floats(Cin, Cout) floats (the transformed filter,
+ * rewritten on every call).  Forward only (I3D is frozen in MGAR-net). */
+long long mgar_conv3d_k3_workspace_floats(int Cin, int Cout);
+int mgar_conv3d_k3_fwd(const float *x, int N, int Cin, int D, int H, int W, const float *w, int Cout, float *w_packed, float *y,
+                       void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).

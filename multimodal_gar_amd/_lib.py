@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libmgar_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -109,6 +109,8 @@ _PROTOS = {
     "mgar_pointwise_conv_fwd": [_P, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
     "mgar_stem_conv3d_workspace_floats": [],
     "mgar_stem_conv3d_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_conv3d_k3_workspace_floats": [_I, _I],
+    "mgar_conv3d_k3_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     "mgar_maxpool3d_same_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_maxpool3d_valid_fwd": [_P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "mgar_roi_align_fwd": [_P, _I, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _P, _P],
@@ -162,7 +164,7 @@ _LONGLONG_RESULTS = frozenset((
     "mgar_bn_stats_from_partials_workspace_floats", "mgar_voxel_roi_pool_stats_workspace_doubles",
     "mgar_voxel_roi_pool_bwd_workspace_floats", "mgar_velodyne_merge_crop_workspace_ints", "mgar_gatv2_bwd_workspace_floats",
     "mgar_fps_batch_buckets_workspace_floats", "mgar_point_grid_workspace_bytes",
-    "mgar_bn_rows_bwd_workspace_floats"))
+    "mgar_bn_rows_bwd_workspace_floats", "mgar_conv3d_k3_workspace_floats"))
 
 _fns = {}
 for _name, _args in _PROTOS.items():

@@ -59,7 +59,7 @@ enum KernelId {
     KT_BN_STATS, KT_BN_APPLY, KT_BN_MAX, KT_BN_BWD_REDUCE, KT_BN_BWD_APPLY, KT_BN_MAX_BWD_REDUCE, KT_BN_MAX_BWD_APPLY,
     KT_POINTWISE_FWD, KT_POINTWISE_DW, KT_ROWMAJOR_DW, KT_MAXPOOL3D, KT_VOXEL_ROI_POOL_FWD, KT_VOXEL_ROI_POOL_BWD, KT_STEM_CONV, KT_QG_INDEX, KT_IMAGE_PREP,
     KT_DAFM_FWD, KT_DAFM_BWD, KT_GATV2_FWD, KT_GATV2_BWD, KT_ROI_ALIGN_FWD, KT_ROI_ALIGN_BWD, KT_VOXEL_QUERY, KT_POINTS_IN_BOXES,
-    KT_ROIPOINT_POOL, KT_SPCONV_INDEX, KT_SPCONV_GEMM, KT_SPCONV_DW, KT_POINT_GRID, KT_BALL_QUERY_GRID, KT_THREE_NN_GRID, KT_COUNT
+    KT_ROIPOINT_POOL, KT_SPCONV_INDEX, KT_SPCONV_GEMM, KT_SPCONV_DW, KT_POINT_GRID, KT_BALL_QUERY_GRID, KT_THREE_NN_GRID, KT_CONV3D_WINO, KT_COUNT
 };
 extern int g_kt_on;
 void kt_begin(int id, hipStream_t st);

@@ -27,7 +27,7 @@ const char *const kKtNames[KT_COUNT] = {
     "pointwise_dw_kernel", "rowmajor_dw_kernel", "maxpool3d_same_kernel", "voxel_roi_pool_fwd", "voxel_roi_pool_bwd", "stem_conv3d_kernel", "query_group_inverse_index",
     "image_resize_normalize",
     "dafm_attn_fwd", "dafm_attn_bwd", "gatv2_fwd", "gatv2_bwd", "roi_align_fwd", "roi_align_bwd", "voxel_query_kernel", "points_in_boxes_kernel",
-    "roipoint_pool3d_kernel", "spconv_index", "spconv_gemm", "spconv_dw", "point_grid_build", "ball_query_grid_kernel", "three_nn_grid_kernel"};
+    "roipoint_pool3d_kernel", "spconv_index", "spconv_gemm", "spconv_dw", "point_grid_build", "ball_query_grid_kernel", "three_nn_grid_kernel", "conv3d_wino_kernel"};
 }  // namespace
 
 void kt_begin(int id, hipStream_t st) {
@@ -53,7 +53,7 @@ void kt_end(int id, hipStream_t st, double bytes, double flops) {
 
 using namespace mgar;
 
-extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 11; }
+extern "C" __attribute__((visibility("default"))) int mgar_abi_version(void) { return 12; }
 extern "C" __attribute__((visibility("default"))) const char *mgar_last_error(void) { return mgar::g_last_error; }
 
 extern "C" __attribute__((visibility("default"))) int mgar_ktimer_enable(int on) {

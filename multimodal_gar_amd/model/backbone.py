@@ -124,11 +124,33 @@ class Unit3D(nn.Module):
                        L.stream_of(x))
         return y
 
+    wino_kernel = True     # 3x3x3, stride 1 on the device: csrc/conv3d_wino.hip (Winograd F(2,3) along W on the fp32 MFMA)
+
+    def _k3_conv(self, x):
+        """The 3x3x3 / stride-1 units (Conv3d_2c_3x3, every Mixed block's Conv3d_0b_3x3) on csrc/conv3d_wino.hip: "same"
+        padding inside the kernel, NCDHW in and out, fp32, forward only; or None (the library convolution then)."""
+        c = self.conv3d
+        if not (self.wino_kernel and x.is_cuda and x.dim() == 5 and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and self._kernel_shape == (3, 3, 3) and self._stride == (1, 1, 1) and c.bias is None and c.groups == 1
+                and c.in_channels % 2 == 0 and x.shape[4] % 2 == 0 and x.is_contiguous() and c.weight.dtype == torch.float32
+                and not (torch.is_grad_enabled() and (x.requires_grad or c.weight.requires_grad))):
+            return None
+        from .. import _lib as L
+        n, cin, d, h, w = x.shape
+        y = torch.empty((n, c.out_channels, d, h, w), dtype=torch.float32, device=x.device)
+        wp = torch.empty((L.raw("mgar_conv3d_k3_workspace_floats", cin, c.out_channels),), dtype=torch.float32, device=x.device)
+        wf = c.weight.detach().contiguous()
+        L.call("mgar_conv3d_k3_fwd", L.fptr(x), n, cin, d, h, w, L.fptr(wf), c.out_channels, L.fptr(wp), L.fptr(y), L.stream_of(x))
+        return y
+
     def _conv(self, x):
         pads = _same_pads(x.shape[2:], self._kernel_shape, self._stride)
         stem = self._stem_conv(x)
         if stem is not None:
             return stem
+        k3 = self._k3_conv(x)
+        if k3 is not None:
+            return k3
         if all(f == b for f, b in pads):
             return F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
         return self.conv3d(F.pad(x, _as_fpad(pads)))

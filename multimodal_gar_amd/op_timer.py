@@ -123,7 +123,7 @@ KERNEL_SOURCES = {
     "ball_query_grid_kernel": "ball_query_grid.hip", "three_nn_grid_kernel": "ball_query_grid.hip", "point_grid_build": "ball_query_grid.hip",
     "spconv_gemm": "sparse_conv.hip", "spconv_dw": "sparse_conv.hip", "spconv_index": "sparse_conv.hip", "gatv2_fwd": "gatv2.hip",
     "gatv2_bwd": "gatv2.hip", "dafm_attn_fwd": "dafm.hip", "dafm_attn_bwd": "dafm.hip", "roi_align_fwd": "roi_align.hip",
-    "roi_align_bwd": "roi_align.hip", "voxel_query_kernel": "voxel_query.hip",
+    "roi_align_bwd": "roi_align.hip", "voxel_query_kernel": "voxel_query.hip", "conv3d_wino_kernel": "conv3d_wino.hip",
 }
 
 
