@@ -492,6 +492,10 @@ int mgar_maxpool3d_valid_fwd(const float *x, int NC, int T, int H, int W, int kt
 int mgar_stem_conv3d_workspace_floats(void);
 int mgar_stem_conv3d_fwd(const float *x, int N, int T, int H, int W, const float *w, float *w_packed, float *y,
                          void *stream);
+/* fp32 with W % 4 == 0 runs the minimal-filtering variant (the stride-2 row convolution split by column parity into a
+ * 3-tap and a 4-tap stride-1 convolution, Winograd F(2, 3) on the 3-tap parts: 10 instead of 14 multiply-accumulates per
+ * (kt, c, kh) and output pair); 0 switches it off (A/B tests), default 1. */
+int mgar_stem_conv3d_set_minimal_filtering(int on);
 
 /* The 3x3x3, stride-1, "same"-padded convolutions of Inception-I3D (model/backbone.py:311-312 ``Conv3d_2c_3x3`` and the
  * ``Conv3d_0b_3x3`` units of every InceptionModule :215-236; Unit3D :134-206 = pad + nn.Conv3d(bias=False)) on the fp32 MFMA

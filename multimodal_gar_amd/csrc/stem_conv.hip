@@ -275,6 +275,188 @@ __global__ void stem_pack_weights_bf16_kernel(const float *__restrict__ w, uint1
     wp[e] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
 }
 
+// ---- fp32, W % 4 == 0: minimal filtering along W ------------------------------------------------------------------------
+// The exact-fp32 MFMA is the bound of this kernel (one 32x32x2 instruction = 64 cycles for one pair of operand registers; LDS,
+// VALU and L2 idle), so multiply-accumulates are what to save.  A stride-2, 7-tap row convolution splits by column parity
+// into a 3-tap stride-1 convolution of the odd columns (taps w1, w3, w5) and a 4-tap one of the even columns (w0, w2, w4, w6)
+// (front padding 2 for even W: input column 2 wo + kw - 2).  For an output PAIR (2p, 2p+1) each 3-tap part is Winograd
+// F(2, 3) -- 4 products instead of 6, transforms made of additions and one halving only, as in csrc/conv3d_wino.hip -- and
+// the fourth even tap is taken directly; its two products ride in the accumulators of components 0 and 3 (y[2p] = m0 + m1 +
+// m2, y[2p+1] = m1 - m2 - m3: m0 enters only y[2p], m3 only y[2p+1]).  10 products per (kt, c, kh) and output pair instead
+// of 14: 36 instead of 50 MFMAs per slab, channel block and 64 outputs.
+//   d^o = odd-column samples  x[2 (2p - 1 + j) + 1 - 2 + ...], d^e = even-column samples, j = 0..3 (d^e also j = 4):
+//   m0 += G0o (d0o - d2o) + G0e (d0e - d2e) + w6 d3e          m1 += G1o (d1o + d2o) + G1e (d1e + d2e)
+//   m3 += G3o (d1o - d3o) + G3e (d1e - d3e) - w6 d4e          m2 += G2o (d2o - d1o) + G2e (d2e - d1e)
+//   G = (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2) of (w1, w3, w5) resp. (w0, w2, w4).
+// Tile: 4 output rows x 64 output columns x 64 channels per workgroup; a wave = one row = 32 pairs x 2 channel blocks x 4
+// components (128 accumulator registers).  The two k of an MFMA are the two parities (half-wave 0 reads the odd-column patch,
+// half-wave 1 the even-column one); the direct taps of two kh share an instruction.  Per (kt, c) slab: 13 x 134 input patch,
+// de-interleaved by parity, and a 4096-float weight block in LDS, double-buffered; global loads of the next slab are issued
+// before the 72 MFMAs of the current one and stored after them (no guards in the staging loops: a guarded LDS store lets the
+// compiler sink the load down to it); operands of step s + 1 are read from LDS before the MFMAs of step s.
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+typedef float __attribute__((ext_vector_type(2))) f32x2;
+constexpr int SW_TH = 4, SW_TWO = 64;                                     // output tile: rows x columns
+constexpr int SW_IH = SCV_S * (SW_TH - 1) + SCV_K;                        // 13 input rows
+constexpr int SW_ICOLS = 134, SW_PITCH = 68;                              // patch columns (67 per parity), LDS pitch per parity row
+constexpr int SW_IN_PER_THREAD = (SW_IH * SW_ICOLS + 255) / 256;          // 7
+constexpr int SW_IN_FLOATS = (SW_IH + 1) * 2 * SW_PITCH;                  // 14 rows allocated: the padded staging slots land in row 13
+constexpr int SW_W_MAIN = SCV_K * 2 * SCV_COUT * 4;                       // [kh][parity][co][t] = 3584
+constexpr int SW_W_FLOATS = SW_W_MAIN + 8 * SCV_COUT;                     // + direct tap [kh 8 (7 + a zero row)][co] = 4096
+constexpr int SW_W_PER_THREAD = SW_W_FLOATS / 4 / 256;                    // 4 x f32x4
+
+__global__ __launch_bounds__(256, 2) void stem_conv3d_wino_kernel(const float *__restrict__ x, const float *__restrict__ wp, StemArgs a,
+                                                                  float *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float s_in[2][SW_IN_FLOATS];
+    __shared__ __attribute__((aligned(16))) float s_w[2][SW_W_FLOATS];
+    const int tiles_w = (a.Wo + SW_TWO - 1) / SW_TWO;
+    const int bx = blockIdx.x % tiles_w, by = blockIdx.x / tiles_w;
+    const int to = blockIdx.y, n = blockIdx.z;
+    const int wo0 = bx * SW_TWO, ho0 = by * SW_TH;
+    const int hbase = SCV_S * ho0 - a.ph, cbase = SCV_S * wo0 - 2;        // first input row / column of the patch (pw = 2)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = lane & 31, h = lane >> 5;
+
+    const int t0 = SCV_S * to - a.pt;
+    const int kt_lo = max(0, -t0), kt_hi = min(SCV_K, a.T - t0);
+    const int nslab = max(0, kt_hi - kt_lo) * SCV_CIN;
+
+    // staging slots of this thread: offset inside an input plane (-1: padding -> zero) and LDS position
+    int off[SW_IN_PER_THREAD], pos[SW_IN_PER_THREAD];
+#pragma unroll
+    for (int u = 0; u < SW_IN_PER_THREAD; ++u) {
+        const int e = threadIdx.x + u * 256;
+        const int ir = e / SW_ICOLS, ic = e - ir * SW_ICOLS;
+        const int hh = hbase + ir, ww = cbase + ic;
+        off[u] = (ir < SW_IH && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? hh * a.W + ww : -1;
+        pos[u] = (ir * 2 + 1 - (ic & 1)) * SW_PITCH + (ic >> 1);           // parity row 0 = odd columns, 1 = even columns
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.f;
+
+    float pin[SW_IN_PER_THREAD];
+    f32x4 pw4[SW_W_PER_THREAD];
+    auto fetch = [&](int slab) {                       // global -> registers; nothing here waits for a load
+        const int kt = kt_lo + slab / SCV_CIN, c = slab % SCV_CIN;
+        const float *plane = x + (((size_t)n * SCV_CIN + c) * a.T + (t0 + kt)) * a.H * a.W;
+#pragma unroll
+        for (int u = 0; u < SW_IN_PER_THREAD; ++u) pin[u] = plane[off[u] < 0 ? 0 : off[u]];
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wp + (size_t)(kt * SCV_CIN + c) * SW_W_FLOATS);
+#pragma unroll
+        for (int u = 0; u < SW_W_PER_THREAD; ++u) pw4[u] = wsrc[threadIdx.x + u * 256];
+    };
+    auto stash = [&](int buf) {                        // registers -> LDS
+#pragma unroll
+        for (int u = 0; u < SW_IN_PER_THREAD; ++u) s_in[buf][pos[u]] = off[u] < 0 ? 0.f : pin[u];
+#pragma unroll
+        for (int u = 0; u < SW_W_PER_THREAD; ++u) reinterpret_cast<f32x4 *>(s_w[buf])[threadIdx.x + u * 256] = pw4[u];
+    };
+
+    if (nslab > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    // lane constants: its parity row of patch row 2 * wave (+ kh), at pair l; the even-column row for the direct taps
+    const int in_lane = (SCV_S * wave * 2 + h) * SW_PITCH + 2 * l;
+    const int ex_lane = (SCV_S * wave * 2 + 1) * SW_PITCH + 2 * l + 3;
+    for (int slab = 0; slab < nslab; ++slab) {
+        const int buf = slab & 1;
+        fetch(min(slab + 1, nslab - 1));               // in flight under the MFMAs below (the last slab re-loads itself: no branch)
+        __builtin_amdgcn_sched_barrier(0);
+        const float *ti = s_in[buf] + in_lane, *te = s_in[buf] + ex_lane;
+        const f32x4 *tw = reinterpret_cast<const f32x4 *>(s_w[buf]) + h * SCV_COUT + l;
+        const float *tx = s_w[buf] + SW_W_MAIN + h * SCV_COUT + l;
+        f32x2 xa[2], xb[2];
+        f32x4 g[2][2];
+        auto read_main = [&](int kh, int slot) {
+            const float *p = ti + kh * 2 * SW_PITCH;
+            xa[slot] = *reinterpret_cast<const f32x2 *>(p);
+            xb[slot] = *reinterpret_cast<const f32x2 *>(p + 2);
+            g[slot][0] = tw[kh * 2 * SCV_COUT];
+            g[slot][1] = tw[kh * 2 * SCV_COUT + 32];
+        };
+        float e3[2], e4[2], gx[2][2];
+        auto read_extra = [&](int i, int slot) {        // direct taps of kh = 2 i + h (kh = 7: zero weights, row 6 again)
+            const float *p = te + min(2 * i + h, SCV_K - 1) * 2 * SW_PITCH;
+            e3[slot] = p[0];
+            e4[slot] = p[1];
+            gx[slot][0] = tx[i * 2 * SCV_COUT];
+            gx[slot][1] = tx[i * 2 * SCV_COUT + 32];
+        };
+        read_main(0, 0);
+#pragma unroll
+        for (int kh = 0; kh < SCV_K; ++kh) {
+            const int slot = kh & 1;
+            if (kh + 1 < SCV_K) read_main(kh + 1, slot ^ 1);
+            else read_extra(0, 0);
+            const float u0 = xa[slot].x - xb[slot].x, u1 = xa[slot].y + xb[slot].x, u2 = xb[slot].x - xa[slot].y, u3 = xa[slot].y - xb[slot].y;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[slot][mb].x, u0, acc[mb][0], 0, 0, 0);
+                acc[mb][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[slot][mb].y, u1, acc[mb][1], 0, 0, 0);
+                acc[mb][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[slot][mb].z, u2, acc[mb][2], 0, 0, 0);
+                acc[mb][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[slot][mb].w, u3, acc[mb][3], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int slot = i & 1;
+            if (i + 1 < 4) read_extra(i + 1, slot ^ 1);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                acc[mb][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(gx[slot][mb], e3[slot], acc[mb][0], 0, 0, 0);
+                acc[mb][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(gx[slot][mb], -e4[slot], acc[mb][3], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        stash(buf ^ 1);                                // the other buffer: its last readers passed the barrier of slab - 1
+        __syncthreads();
+    }
+    // output transform + store: register r of a lane = (co = 32 mb + (r & 3) + 8 (r >> 2) + 4 h, pair l)
+    const int ho = ho0 + wave, wo = wo0 + 2 * l;
+    if (ho < a.Ho && wo < a.Wo) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float m0 = acc[mb][0][r], m1 = acc[mb][1][r], m2 = acc[mb][2][r], m3 = acc[mb][3][r];
+                f32x2 o;
+                o.x = (m0 + m1) + m2;
+                o.y = (m1 - m2) - m3;
+                *reinterpret_cast<f32x2 *>(y + ((((size_t)n * SCV_COUT + co) * a.To + to) * a.Ho + ho) * a.Wo + wo) = o;
+            }
+    }
+}
+
+// (64, 3, 7, 7, 7) -> [kt][c][ [kh 7][parity 2: odd taps (w1,w3,w5) / even taps (w0,w2,w4)][co 64][t 4] | [kh 8][co 64]: w6, row 7 = 0 ]
+__global__ void stem_pack_weights_wino_kernel(const float *__restrict__ w, float *__restrict__ wp) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= SCV_K * SCV_CIN * SW_W_FLOATS) return;
+    const int slab = e / SW_W_FLOATS, r = e - slab * SW_W_FLOATS;
+    const int kt = slab / SCV_CIN, c = slab - kt * SCV_CIN;
+    float v = 0.f;
+    if (r < SW_W_MAIN) {
+        const int t = r & 3, co = (r >> 2) % SCV_COUT, par = (r / (4 * SCV_COUT)) & 1, kh = r / (8 * SCV_COUT);
+        const float *src = w + ((((size_t)co * SCV_CIN + c) * SCV_K + kt) * SCV_K + kh) * SCV_K;
+        const float g0 = par ? src[0] : src[1], g1 = par ? src[2] : src[3], g2 = par ? src[4] : src[5];
+        v = t == 0 ? g0 : (t == 3 ? g2 : (t == 1 ? 0.5f * ((g0 + g2) + g1) : 0.5f * ((g0 + g2) - g1)));
+    } else {
+        const int q = r - SW_W_MAIN, co = q % SCV_COUT, kh = q / SCV_COUT;
+        if (kh < SCV_K) v = w[((((size_t)co * SCV_CIN + c) * SCV_K + kt) * SCV_K + kh) * SCV_K + 6];
+    }
+    wp[e] = v;
+}
+
+static int g_stem_minimal_filtering = 1;
+
 template <typename T>
 static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *w, float *w_packed, T *y, void *stream) {
     MGAR_REQUIRE(N >= 0 && Tn > 0 && H > 0 && W > 0, "stem_conv3d_fwd: bad sizes");
@@ -298,6 +480,16 @@ static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *
                            reinterpret_cast<const u32x4 *>(w_packed), a, reinterpret_cast<bf16_t *>(y));
         return check_launch("stem_conv3d_fwd: launch failed");
     }
+    if (!Payload<T>::is_bf16 && g_stem_minimal_filtering && W % 4 == 0) {      // even W (front padding 2) and whole output pairs
+        hipLaunchKernelGGL(stem_pack_weights_wino_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SW_W_FLOATS, 256)), dim3(256), 0, st, w, w_packed);
+        const int wtiles = ((a.Wo + SW_TWO - 1) / SW_TWO) * ((a.Ho + SW_TH - 1) / SW_TH);
+        // flops: the MFMA work issued = 10/14 of the direct convolution's (bench.py prices the kernel against the MFMA peak)
+        KtScope kt(KT_STEM_CONV, st, (double)sizeof(T) * ((double)N * SCV_CIN * Tn * H * W + outs * SCV_COUT),
+                   2.0 * outs * SCV_COUT * SCV_CIN * SCV_K * SCV_K * 5.0);
+        hipLaunchKernelGGL(stem_conv3d_wino_kernel, dim3(wtiles, a.To, N), dim3(256), 0, st, reinterpret_cast<const float *>(x),
+                           (const float *)w_packed, a, reinterpret_cast<float *>(y));
+        return check_launch("stem_conv3d_fwd: launch failed");
+    }
     hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(ceil_div(SCV_K * SCV_CIN * SCV_W_FLOATS, 256)), dim3(256), 0, st, w, w_packed);
     {
         KtScope kt(KT_STEM_CONV, st, (double)sizeof(T) * ((double)N * SCV_CIN * Tn * H * W + outs * SCV_COUT),
@@ -315,7 +507,9 @@ using namespace mgar;
 
 // x (N, 3, T, H, W), w (64, 3, 7, 7, 7) -> y (N, 64, ceil(T/2), ceil(H/2), ceil(W/2)); w_packed: caller-allocated scratch of
 // mgar_stem_conv3d_workspace_floats() floats (the weights re-laid out for the kernel, rewritten on every call).
-SCV_API int mgar_stem_conv3d_workspace_floats(void) { return SCV_K * SCV_CIN * SCV_W_FLOATS; }
+SCV_API int mgar_stem_conv3d_workspace_floats(void) { return SCV_K * SCV_CIN * (SW_W_FLOATS > SCV_W_FLOATS ? SW_W_FLOATS : SCV_W_FLOATS); }
+// A/B switch (tests, tools): 0 = the direct kernel for fp32 too; default 1 = minimal filtering along W where W % 4 == 0
+SCV_API int mgar_stem_conv3d_set_minimal_filtering(int on) { g_stem_minimal_filtering = on ? 1 : 0; return MGAR_OK; }
 SCV_API int mgar_stem_conv3d_fwd(const float *x, int N, int T, int H, int W, const float *w, float *w_packed, float *y, void *stream) {
     return stem_conv_impl<float>(x, N, T, H, W, w, w_packed, y, stream);
 }

@@ -90,3 +90,35 @@ def test_unit3d_takes_the_kernel_and_matches_the_library():
     assert err <= 5e-6 * scale
     xr = x.clone().requires_grad_(True)
     assert u._k3_conv(xr) is None          # a trained trunk keeps the library convolution (autograd)
+
+
+@pytest.mark.parametrize("shape", [(1, 5, 24, 640), (2, 15, 64, 96), (1, 4, 30, 132), (1, 2, 10, 8)])
+def test_stem_minimal_filtering_against_float64_and_the_direct_kernel(shape):
+    """csrc/stem_conv.hip, fp32, W % 4 == 0: the parity-split / F(2,3) variant against the fp64 convolution, with the direct
+    kernel (switch off) measured beside it -- same error class; wide rows (5 column tiles), ragged tiles, tiny volumes."""
+    from multimodal_gar_amd import _lib as L
+    from multimodal_gar_amd.model.backbone import Unit3D
+    n, t, h, w = shape
+    torch.manual_seed(11)
+    u = Unit3D(3, 64, [7, 7, 7], stride=(2, 2, 2), padding=(3, 3, 3), use_batch_norm=False, activation_fn=None).cuda()
+    x = torch.randn(n, 3, t, h, w, device="cuda")
+    pads = []
+    for size in (w, h, t):
+        total = 5 if size % 2 == 0 else 6
+        pads += [total // 2, total - total // 2]
+    with torch.no_grad():
+        want = F.conv3d(F.pad(x.double().cpu(), pads), u.conv3d.weight.double().cpu(), stride=2)
+        got = u(x).double().cpu()
+        L.call("mgar_stem_conv3d_set_minimal_filtering", 0)
+        try:
+            direct = u(x).double().cpu()
+        finally:
+            L.call("mgar_stem_conv3d_set_minimal_filtering", 1)
+    scale = want.abs().max().item()
+    e_k, e_d = (got - want).abs().max().item(), (direct - want).abs().max().item()
+    record_error("stem minimal filtering vs fp64", e_k, scale, 5e-6)
+    record_error("stem direct kernel vs fp64", e_d, scale, 5e-6)
+    assert got.shape == want.shape
+    assert e_k <= 5e-6 * scale, (e_k, e_d, scale)
+    assert e_k <= max(4.0 * e_d, 2e-6 * scale)
+    assert (got - direct).abs().max().item() > 0 or n * t * h * w < 1000     # (the two kernels really are different code paths)
