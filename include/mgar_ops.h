@@ -504,6 +504,7 @@ int mgar_stem_conv3d_set_minimal_filtering(int on);
  * even.  w_packed: caller-allocated scratch of mgar_conv3d_k3_workspace_floats(Cin, Cout) floats (the transformed filter,
  * rewritten on every call).  Forward only (I3D is frozen in MGAR-net). */
 long long mgar_conv3d_k3_workspace_floats(int Cin, int Cout);
+int mgar_conv3d_k3_set_lds_pad(int bytes);   /* diagnostics: extra dynamic LDS per workgroup (occupancy experiments), default 0 */
 int mgar_conv3d_k3_fwd(const float *x, int N, int Cin, int D, int H, int W, const float *w, int Cout, float *w_packed, float *y,
                        void *stream);
 

@@ -218,6 +218,10 @@ __global__ void conv3d_wino_filter_kernel(const float *__restrict__ w, int Cin, 
     reinterpret_cast<float4 *>(wt)[e] = g;
 }
 
+// Extra dynamic LDS per workgroup (bytes): > 20 KB leaves one workgroup per CU (tools/overlap_probe.py measures how much of
+// a concurrent HBM-bound stream then runs beside this MFMA-bound kernel).  0 by default.
+static int g_cw_lds_pad = 0;
+
 template <int PW>
 static void cw_launch(const float *x, const float *wt, CwArgs a, float *y, hipStream_t st) {
     typedef CwGeom<PW> G;
@@ -230,13 +234,13 @@ static void cw_launch(const float *x, const float *wt, CwArgs a, float *y, hipSt
         a.cg0 = 0; a.ncg = groups - tail;
         a.total = tiles * a.ncg;
         a.per_xcd = (int)((a.total + 7) / 8);
-        hipLaunchKernelGGL((conv3d_wino_kernel<PW, 2>), dim3(a.per_xcd * 8), dim3(256), 0, st, x, wt, a, y);
+        hipLaunchKernelGGL((conv3d_wino_kernel<PW, 2>), dim3(a.per_xcd * 8), dim3(256), g_cw_lds_pad, st, x, wt, a, y);
     }
     if (tail) {
         a.cg0 = groups - 1; a.ncg = 1;
         a.total = tiles;
         a.per_xcd = (int)((a.total + 7) / 8);
-        hipLaunchKernelGGL((conv3d_wino_kernel<PW, 1>), dim3(a.per_xcd * 8), dim3(256), 0, st, x, wt, a, y);
+        hipLaunchKernelGGL((conv3d_wino_kernel<PW, 1>), dim3(a.per_xcd * 8), dim3(256), g_cw_lds_pad, st, x, wt, a, y);
     }
 }
 
@@ -250,6 +254,12 @@ using namespace mgar;
 CW_API long long mgar_conv3d_k3_workspace_floats(int Cin, int Cout) {
     if (Cin <= 0 || Cout <= 0) return 0;
     return (long long)ceil_div(Cout, CW_CG) * CW_CG * Cin * 36;
+}
+
+CW_API int mgar_conv3d_k3_set_lds_pad(int bytes) {
+    MGAR_REQUIRE(bytes >= 0 && bytes <= 90 * 1024, "conv3d_k3_set_lds_pad: 0 .. 92160 bytes");
+    g_cw_lds_pad = bytes;
+    return MGAR_OK;
 }
 
 // x (N, Cin, D, H, W) fp32 NCDHW, w (Cout, Cin, 3, 3, 3) -> y (N, Cout, D, H, W): stride 1, zero padding 1 on every side.

@@ -124,6 +124,7 @@ class Unit3D(nn.Module):
                        L.stream_of(x))
         return y
 
+    gemm_1x1 = True        # 1x1x1 units on the device: a strided-batched GEMM instead of the library convolution
     wino_kernel = True     # 3x3x3, stride 1 on the device: csrc/conv3d_wino.hip (Winograd F(2,3) along W on the fp32 MFMA)
 
     def _k3_conv(self, x):
@@ -151,6 +152,13 @@ class Unit3D(nn.Module):
         k3 = self._k3_conv(x)
         if k3 is not None:
             return k3
+        if (self.gemm_1x1 and x.is_cuda and x.dim() == 5 and self._kernel_shape == (1, 1, 1) and self._stride == (1, 1, 1)
+                and x.is_contiguous() and self.conv3d.groups == 1 and not torch.is_autocast_enabled()
+                and x.dtype == self.conv3d.weight.dtype):
+            # a 1x1x1 convolution is the GEMM W (C_out, C_in) x (C_in, T*H*W) per sample: one strided-batched library GEMM on the
+            # NCDHW tensor as it lies (MIOpen wraps its NDHWC kernels in two layout transposes and needs a find pass per shape)
+            from ..nn_utils import conv1x1
+            return conv1x1(self.conv3d, x)
         if all(f == b for f, b in pads):
             return F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
         return self.conv3d(F.pad(x, _as_fpad(pads)))

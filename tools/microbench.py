@@ -119,6 +119,11 @@ def main():
             rec("pointwise_conv_fwd bn+relu %d->%d P=%d" % (cin, cout, p), timeit(fn, a.iters), (x.numel() + y.numel()) * 4)
             we = w.unsqueeze(0).expand(f, -1, -1)
             rec("   library bmm %d->%d (no activation)" % (cin, cout), timeit(lambda: torch.bmm(we, x, out=y), a.iters), (x.numel() + y.numel()) * 4)
+            # the layer's data gradient through the same kernel: dX = W^T dY, identity activation
+            dy = y; dx = x
+            fn2 = lambda: L.call("mgar_pointwise_conv_fwd", L.fptr(dy), f, cout, p, L.fptr(w), 1, cin, cin, None, None, None, None, 0,  # noqa: E731
+                                 L.fptr(dx), L.stream_of(dy))
+            rec("   dX = W^T dY %d->%d" % (cout, cin), timeit(fn2, a.iters), (x.numel() + y.numel()) * 4)
             del x, y
 
 
