@@ -34,7 +34,7 @@ KERNELS = {
     "roi_align_bwd": "mgar::roi_align_bwd_kernel", "voxel_query_kernel": "mgar::voxel_query_kernel", "three_nn_kernel": "mgar::three_nn_kernel",
     "three_interp_fwd": "mgar::three_interp_batch_fwd", "three_interp_bwd": "mgar::three_interp_batch_bwd",
     "query_group_fwd": "mgar::qg_", "query_group_bwd": "mgar::qg_", "query_group_inverse_index": "mgar::qg_inv_",
-    "stem_conv3d_kernel": "mgar::stem_conv3d_kernel", "conv3d_wino_kernel": "mgar::conv3d_wino_kernel", "voxel_roi_pool_fwd": "mgar::vrp_fwd_kernel", "voxel_roi_pool_bwd": "mgar::vrp_bwd_kernel",
+    "stem_conv3d_kernel": "mgar::stem_conv3d_", "conv3d_wino_kernel": "mgar::conv3d_wino_kernel", "voxel_roi_pool_fwd": "mgar::vrp_fwd_kernel", "voxel_roi_pool_bwd": "mgar::vrp_bwd_kernel",
 }
 WIDE_READERS = {"bn_partial_kernel", "bn_apply_kernel", "bn_max_vec_kernel", "bn_bwd_partial_kernel", "bn_bwd_apply_kernel",
                 "bn_max_bwd_apply_kernel", "pointwise_fwd_kernel", "pointwise_dw_kernel", "maxpool3d_same_kernel"}

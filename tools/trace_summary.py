@@ -16,6 +16,8 @@ def category(n):
         return "library GEMM"
     if "_ZN2ck" in n or "Im3d2Col" in n or "batched_transpose" in n:
         return "library conv (MIOpen/CK)"
+    if "mgar::conv3d_wino" in n or "mgar::stem_conv3d" in n:
+        return "mgar convolution (fp32 MFMA)"
     if "mgar::bn_" in n:
         return "mgar bn_act"
     if "mgar::pointwise_" in n or "mgar::rowmajor_dw" in n:
