@@ -47,6 +47,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// A raw buffer resource over `bytes` bytes at a wave-uniform address (the address is pinned to scalar registers: a descriptor the
+// compiler cannot prove uniform costs a waterfall loop around every load).  Loads at an offset >= bytes return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_buffer(const void *p, int bytes) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 void set_error(const char *msg);
 
 // ---- optional per-kernel timing (bench.py's roofline table) --------------------------------------

@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(const float *__rest
 
     const int HW = a.H * a.W;
     const long long DHW = (long long)a.D * HW;
-    // per-thread gather offsets of the halo tile relative to the first channel of a pair (-1: outside the volume -> zero)
+    // per-thread gather offsets of the halo tile relative to the first channel of a pair.  The tile is read through a raw buffer
+    // resource over the two channels of the pair: an offset outside its range (the padding: -1 = 0xffffffff) returns 0 from the
+    // hardware's bounds check, so the staging path has no address arithmetic and no select (vector instructions do not overlap
+    // the MFMAs here: every one of them is MFMA time)
     int off[G::IN_PER_THREAD];
 #pragma unroll
     for (int u = 0; u < G::IN_PER_THREAD; ++u) {
@@ -94,9 +97,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(const float *__rest
         const int iy = r1 / G::IW, ix = r1 - iy * G::IW;
         const int dd = d - 1 + dz, hh = h0 - 1 + iy, ww = w0 - 1 + ix;
         const bool ok = e < G::IN_FLOATS && dd >= 0 && dd < a.D && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W;
-        off[u] = ok ? (int)(c * DHW) + dd * HW + hh * a.W + ww : -1;
+        off[u] = ok ? 4 * ((int)(c * DHW) + dd * HW + hh * a.W + ww) : -1;   // BYTE offset; -1 = beyond the buffer's range -> reads 0
     }
     const float *xin = x + (long long)n * a.Cin * DHW;
+    const int pair_bytes = (int)(8 * DHW);             // two channels
     const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wt) + (long long)cg * (a.Cin / 2) * (CW_W_FLOATS / 4);
 
     f32x16 acc[NMB][4];
@@ -110,10 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(const float *__rest
     float pin[G::IN_PER_THREAD];
     f32x4 pw4[CW_W_PER_THREAD];    // (native vector types: arrays of HIP's float4 structs are not split into registers here)
     auto fetch = [&](int j) {                          // global -> registers: channel pair j
-        const float *src = xin + (long long)(2 * j) * DHW;
+        const __amdgpu_buffer_rsrc_t src = uniform_buffer(xin + (long long)(2 * j) * DHW, pair_bytes);
 #pragma unroll
-        for (int u = 0; u < G::IN_PER_THREAD; ++u)     // unconditional loads (offset 0 is always valid; zero is selected in stash()): no branches,
-            pin[u] = src[off[u] < 0 ? 0 : off[u]];     // and nothing here waits for a load
+        for (int u = 0; u < G::IN_PER_THREAD; ++u)     // nothing here waits for a load
+            pin[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, off[u], 0, 0));
 
         const f32x4 *ws = wsrc + (long long)j * (CW_W_FLOATS / 4);
 #pragma unroll
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_wino_kernel(const float *__rest
     auto stash = [&](int buf) {                        // registers -> LDS
 #pragma unroll
         for (int u = 0; u < G::IN_PER_THREAD; ++u) {
-            s_in[buf][threadIdx.x + u * 256] = off[u] < 0 ? 0.f : pin[u];
+            s_in[buf][threadIdx.x + u * 256] = pin[u];
         }
 #pragma unroll
         for (int u = 0; u < CW_W_PER_THREAD; ++u) {
@@ -270,7 +274,7 @@ CW_API int mgar_conv3d_k3_fwd(const float *x, int N, int Cin, int D, int H, int 
     MGAR_REQUIRE(Cin % 2 == 0 && W % 2 == 0, "conv3d_k3_fwd: Cin and W must be even");
     if (N == 0) return MGAR_OK;
     MGAR_REQUIRE(x && w && w_packed && y, "conv3d_k3_fwd: null pointer");
-    MGAR_REQUIRE((long long)2 * D * H * W < (1ll << 31), "conv3d_k3_fwd: volume too large for 32-bit tile offsets");
+    MGAR_REQUIRE((long long)8 * D * H * W < (1ll << 31), "conv3d_k3_fwd: volume too large for 32-bit tile offsets");
     hipStream_t st = (hipStream_t)stream;
     CwArgs a{N, Cin, D, H, W, Cout, ceil_div(Cout, CW_CG), 0, 0, 0, 0, 0};
     const long long wtotal = (long long)a.ncg * (Cin / 2) * 9 * 2 * CW_CG;      // float4 elements

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void stem_conv3d_wino_kernel(const float *_
         const int e = threadIdx.x + u * 256;
         const int ir = e / SW_ICOLS, ic = e - ir * SW_ICOLS;
         const int hh = hbase + ir, ww = cbase + ic;
-        off[u] = (ir < SW_IH && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? hh * a.W + ww : -1;
+        off[u] = (ir < SW_IH && hh >= 0 && hh < a.H && ww >= 0 && ww < a.W) ? 4 * (hh * a.W + ww) : -1;   // byte offset; -1: reads 0
         pos[u] = (ir * 2 + 1 - (ic & 1)) * SW_PITCH + (ic >> 1);           // parity row 0 = odd columns, 1 = even columns
     }
 
@@ -344,16 +344,18 @@ __global__ __launch_bounds__(256, 2) void stem_conv3d_wino_kernel(const float *_
     f32x4 pw4[SW_W_PER_THREAD];
     auto fetch = [&](int slab) {                       // global -> registers; nothing here waits for a load
         const int kt = kt_lo + slab / SCV_CIN, c = slab % SCV_CIN;
-        const float *plane = x + (((size_t)n * SCV_CIN + c) * a.T + (t0 + kt)) * a.H * a.W;
+        // the plane through a raw buffer resource: the padding's offset (-1) is out of range and reads 0 -- no select, no 64-bit
+        // address arithmetic in the staging path
+        const __amdgpu_buffer_rsrc_t plane = uniform_buffer(x + (((size_t)n * SCV_CIN + c) * a.T + (t0 + kt)) * a.H * a.W, 4 * a.H * a.W);
 #pragma unroll
-        for (int u = 0; u < SW_IN_PER_THREAD; ++u) pin[u] = plane[off[u] < 0 ? 0 : off[u]];
+        for (int u = 0; u < SW_IN_PER_THREAD; ++u) pin[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(plane, off[u], 0, 0));
         const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wp + (size_t)(kt * SCV_CIN + c) * SW_W_FLOATS);
 #pragma unroll
         for (int u = 0; u < SW_W_PER_THREAD; ++u) pw4[u] = wsrc[threadIdx.x + u * 256];
     };
     auto stash = [&](int buf) {                        // registers -> LDS
 #pragma unroll
-        for (int u = 0; u < SW_IN_PER_THREAD; ++u) s_in[buf][pos[u]] = off[u] < 0 ? 0.f : pin[u];
+        for (int u = 0; u < SW_IN_PER_THREAD; ++u) s_in[buf][pos[u]] = pin[u];
 #pragma unroll
         for (int u = 0; u < SW_W_PER_THREAD; ++u) reinterpret_cast<f32x4 *>(s_w[buf])[threadIdx.x + u * 256] = pw4[u];
     };
@@ -468,6 +470,7 @@ static int stem_conv_impl(const T *x, int N, int Tn, int H, int W, const float *
     };
     StemArgs a{N, Tn, H, W, (Tn + 1) / 2, (H + 1) / 2, (W + 1) / 2, front(Tn), front(H), front(W)};
     MGAR_REQUIRE(a.To <= 65535 && N <= 65535, "stem_conv3d_fwd: T or N too large");
+    MGAR_REQUIRE((long long)4 * H * W < (1ll << 31), "stem_conv3d_fwd: frame too large for 32-bit plane offsets");
     hipStream_t st = (hipStream_t)stream;
     const int tiles = ((a.Wo + SCV_TW - 1) / SCV_TW) * ((a.Ho + SCV_TH - 1) / SCV_TH);
     const double outs = (double)N * a.To * a.Ho * a.Wo;
