@@ -508,6 +508,10 @@ int mgar_conv3d_k3_set_lds_pad(int bytes);   /* diagnostics: extra dynamic LDS p
 int mgar_conv3d_k3_fwd(const float *x, int N, int Cin, int D, int H, int W, const float *w, int Cout, float *w_packed, float *y,
                        void *stream);
 
+/* A timed gap on a stream: one wave sleeping `us` (0 .. 1000) microseconds.  Scheduling aid of the two-stream clip model
+ * (workload.ClipModel.forward): the RGB side stream starts a few microseconds after the level-1 FPS launch. */
+int mgar_delay_us(int us, void *stream);
+
 /* ===================== third-party ops on the hot path ================================ */
 
 /* torchvision.ops.roi_align (call site model/gat_model.py:1056-1057, sg_model.py:96-97).

@@ -110,6 +110,7 @@ _PROTOS = {
     "mgar_stem_conv3d_workspace_floats": [],
     "mgar_stem_conv3d_set_minimal_filtering": [_I],
     "mgar_stem_conv3d_fwd": [_P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "mgar_delay_us": [_I, _P],
     "mgar_conv3d_k3_workspace_floats": [_I, _I],
     "mgar_conv3d_k3_set_lds_pad": [_I],
     "mgar_conv3d_k3_fwd": [_P, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P],

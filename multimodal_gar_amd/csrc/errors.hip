@@ -101,3 +101,22 @@ extern "C" __attribute__((visibility("default"))) int mgar_ktimer_read(int id, d
     if (reset) { s.ms = s.bytes = s.flops = 0.0; s.launches = 0; }
     return MGAR_OK;
 }
+
+// ---- a timed gap on a stream ------------------------------------------------------------------------------------------------
+// One wave that sleeps for `us` microseconds (constant 100 MHz wall clock; bounded, no memory polling).  The clip model puts
+// it at the head of the RGB side stream, behind an event recorded just before the level-1 FPS launch: a 1024-thread workgroup
+// per cloud needs half a CU at once, and once the I3D stem's tens of thousands of workgroups are being dispatched the freed
+// slots go to the stem's next workgroups -- measured, the sampling then starts when the stem ENDS (4.6 -> 13.9 ms, and the whole
+// LiDAR branch behind it).  A few microseconds of head start let its workgroups become resident first.
+namespace mgar {
+__global__ void delay_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace mgar
+extern "C" __attribute__((visibility("default"))) int mgar_delay_us(int us, void *stream) {
+    MGAR_REQUIRE(us >= 0 && us <= 1000, "delay_us: 0 .. 1000 microseconds");
+    if (us == 0) return MGAR_OK;
+    hipLaunchKernelGGL(mgar::delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)us * 100);
+    return check_launch("delay_us: launch failed");
+}

@@ -75,6 +75,11 @@ def farthest_point_sampling_wrapper(b, n, m, points, temp, idx):
     return 1
 
 
+# Called (if set) on the launching stream right before the sampling kernel of farthest_point_sampling_pruned_wrapper goes out --
+# after its Morton-order preparation.  workload.ClipModel records an event there that the RGB side stream waits for.
+BEFORE_SAMPLING_LAUNCH = None
+
+
 def farthest_point_sampling_pruned_wrapper(b, n, m, points, temp, idx):
     """Same result as farthest_point_sampling_wrapper; points are visited in Morton order so that whole waves can
     skip the distance update of a round (csrc/fps.hip, fps_pruned_kernel).  1024 <= n <= 16384."""
@@ -82,6 +87,8 @@ def farthest_point_sampling_pruned_wrapper(b, n, m, points, temp, idx):
     codes = torch.empty((b, n), dtype=torch.int32, device=points.device)
     L.call("mgar_morton_codes", b, n, L.fptr(points), L.iptr(codes), L.stream_of(points))
     perm = torch.sort(codes, dim=1).indices.int()
+    if BEFORE_SAMPLING_LAUNCH is not None:
+        BEFORE_SAMPLING_LAUNCH()
     L.call("mgar_fps_batch_perm", b, n, m, L.fptr(points), L.fptr(temp), L.iptr(perm), L.iptr(idx), L.stream_of(points))
     return 1
 

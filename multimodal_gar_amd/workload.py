@@ -23,6 +23,7 @@ Data parallelism: the clip batch is sharded across ranks (one process per GPU); 
 all-reduced by DistributedDataParallel over RCCL.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -148,6 +149,8 @@ class ClipModel(nn.Module):
         # (4.6 ms on 15 workgroups at one clip per rank) off the critical path.  Off by default: the headline numbers are the
         # un-pipelined step.
         self.geometry_prefetch = False
+        # Microseconds by which the RGB side stream starts after the level-1 FPS kernel has gone out (see forward()); 0 = off
+        self.sampling_head_start_us = int(os.environ.get("MGAR_SAMPLING_HEAD_START_US", 20))
         self._geo_cur = None        # geometry of the batch this step consumes (computed during the previous step)
         self._geo_next = None       # geometry being computed for the next step (owned by the side stream until finish_prefetch)
 
@@ -261,8 +264,24 @@ class ClipModel(nn.Module):
                 # the NEXT batch's geometry (the caller passes its points; the benchmark's batches are all the same tensor)
                 self._geo_next = trunk.geometry(batch.get("next_points", batch["points"]), self._geo_stream)
             else:
-                geometry = self.trunk_geometry(batch["points"], self._geo_stream if self.geometry_ahead == "all" else main)   # FPS first
+                geometry = None
+            from . import _lib as L
+            from .pcdet.ops.pointnet2.pointnet2_batch import pointnet2_batch_cuda as shim
+            sampling_goes_out = []
+            if not prefetch and self.sampling_head_start_us > 0:
+                # The level-1 FPS (one 1024-thread workgroup per cloud, the head of the LiDAR chain) has to be RESIDENT before the
+                # I3D stem's workgroups start streaming through the CUs, or it starts when the stem ends (csrc/errors.hip,
+                # mgar_delay_us): the side stream waits for the moment the sampling kernel goes out, plus a few microseconds.
+                shim.BEFORE_SAMPLING_LAUNCH = lambda: sampling_goes_out.append(torch.cuda.current_stream().record_event())
+            try:
+                if not prefetch:
+                    geometry = self.trunk_geometry(batch["points"], self._geo_stream if self.geometry_ahead == "all" else main)   # FPS first
+            finally:
+                shim.BEFORE_SAMPLING_LAUNCH = None
             self._side_stream.wait_event(inputs_ready)
+            if sampling_goes_out:
+                self._side_stream.wait_event(sampling_goes_out[0])
+                L.call("mgar_delay_us", int(self.sampling_head_start_us), self._side_stream.cuda_stream)
             with torch.cuda.stream(self._side_stream):
                 crops = self.rgb_crops(batch["images"], batch["bboxes"])
             lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], geometry)   # (B*T, A, 512)
