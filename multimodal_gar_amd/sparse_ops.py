@@ -54,10 +54,20 @@ class VoxelHash:
 
 class Rulebook:
     """Neighbour tables of one (input sites, kernel, stride, padding) combination; shared by every convolution with the
-    same ``indice_key`` (as spconv shares its indice pairs)."""
+    same ``indice_key`` (as spconv shares its indice pairs).
 
-    def __init__(self, indices, spatial_shape, batch_size, kernel, stride, padding, subm):
+    Precondition (spconv's as well): the rows of ``indices`` are UNIQUE voxel coordinates -- what a voxeliser produces
+    (csrc/voxel_hash.hpp keeps the smallest row of a duplicated coordinate, so a duplicate would simply never be read; but the
+    pair-list data gradient, csrc/sparse_conv.hip spconv_pairs_gemm_kernel, accumulates per input row without atomics and relies on
+    every (output, offset) pair naming one row).  ``check_unique=True`` asserts it with one sort (off by default: a host sync)."""
+
+    def __init__(self, indices, spatial_shape, batch_size, kernel, stride, padding, subm, check_unique=False):
         import ctypes
+        if check_unique and indices.shape[0] > 1:
+            sz, sy, sx = (int(v) for v in spatial_shape)
+            key = ((indices[:, 0].long() * sz + indices[:, 1].long()) * sy + indices[:, 2].long()) * sx + indices[:, 3].long()
+            if torch.unique(key).numel() != key.numel():
+                raise ValueError("sparse convolution: duplicate voxel coordinates in the input indices")
         self.kernel, self.stride, self.padding, self.subm = _triple(kernel), _triple(stride), _triple(padding), bool(subm)
         kz, ky, kx = self.kernel
         self.K = kz * ky * kx

@@ -262,3 +262,12 @@ def test_register_gather_kernel_equals_lds_kernel(cin, cout, flip):
         has = nb[:, k] >= 0
         want[has] += feats[nb[has, k]].double() @ wk
     assert (a.double() - want).abs().max().item() <= 2e-5 * (want.abs().max().item() + 1e-6)
+
+
+def test_rulebook_rejects_duplicate_coordinates_when_asked():
+    """the sparse kernels assume unique voxel coordinates (as spconv does); Rulebook(check_unique=True) asserts it."""
+    from multimodal_gar_amd.sparse_ops import Rulebook
+    idx = torch.tensor([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 3]], dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        Rulebook(idx, (4, 8, 8), 1, 3, 1, 1, True, check_unique=True)
+    Rulebook(idx[:2].contiguous(), (4, 8, 8), 1, 3, 1, 1, True, check_unique=True)
