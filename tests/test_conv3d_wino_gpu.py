@@ -122,3 +122,36 @@ def test_stem_minimal_filtering_against_float64_and_the_direct_kernel(shape):
     assert e_k <= 5e-6 * scale, (e_k, e_d, scale)
     assert e_k <= max(4.0 * e_d, 2e-6 * scale)
     assert (got - direct).abs().max().item() > 0 or n * t * h * w < 1000     # (the two kernels really are different code paths)
+
+
+def test_i3d_trunk_with_own_convolutions_matches_the_library_route():
+    """InceptionI3d.extract_features (to Mixed_4f, frozen, train-mode BatchNorm with per-clip statistics) with the round-3 routes --
+    minimal-filtering stem, F(2,3) 3x3x3 units, 1x1x1 units as batched GEMMs -- against the same module on the library's
+    convolutions: 17 convolution + BatchNorm levels deep, the two outputs agree to 3.5e-5 of the feature scale (tolerance 1e-4)."""
+    from multimodal_gar_amd import _lib as L
+    from multimodal_gar_amd.model.backbone import InceptionI3d, Unit3D
+    torch.manual_seed(21)
+    net = InceptionI3d(final_endpoint="Mixed_4f")
+    net.build()
+    net = net.cuda().train()
+    net.set_per_sample_stats(True)
+    x = torch.randn(2, 3, 9, 96, 160, device="cuda")
+    units = [m for m in net.modules() if isinstance(m, Unit3D)]
+    with torch.no_grad():
+        own = net.extract_features(x)
+        for u in units:
+            u.wino_kernel = False
+            u.gemm_1x1 = False
+        L.call("mgar_stem_conv3d_set_minimal_filtering", 0)
+        try:
+            lib = net.extract_features(x)
+        finally:
+            L.call("mgar_stem_conv3d_set_minimal_filtering", 1)
+            for u in units:
+                u.wino_kernel = True
+                u.gemm_1x1 = True
+    assert own.shape == lib.shape == (2, 832, 3, 6, 10)
+    scale = lib.abs().max().item()
+    err = (own - lib).abs().max().item()
+    record_error("I3D to Mixed_4f: own convolutions vs library route", err, scale, 1e-4)
+    assert err <= 1e-4 * scale, (err, scale)
