@@ -87,6 +87,9 @@ def parse():
     ap.add_argument("--ddp-wrapper", action="store_true",
                     help="eager DistributedDataParallel (bucketed all-reduce overlapped with backward) instead of one flattened "
                          "gradient all-reduce after the backward; implies --no-graph (DDP hooks cannot be captured)")
+    ap.add_argument("--prefetch-rgb", action="store_true",
+                    help="software-pipeline the FROZEN RGB branch: every step runs I3D + RoIAlign for the NEXT batch under its own "
+                         "backward instead of beside the LiDAR forward (same work per step; off by default)")
     ap.add_argument("--prefetch-geometry", action="store_true",
                     help="input-side software pipelining (off by default): every step computes the PointNet++ trunk's coordinate-only "
                          "work (FPS, ball queries, 3-NN weights) for the NEXT batch on a side stream while it runs the feature path and "
@@ -464,6 +467,7 @@ def main():
         step.module.overlap_branches = not args.no_overlap and not args.no_graph and not args.ddp_wrapper
         step.module.i3d_channels_last = bool(args.i3d_channels_last)
         step.module.geometry_prefetch = bool(args.prefetch_geometry) and args.mode == "train"
+        step.module.rgb_prefetch = bool(args.prefetch_rgb) and args.mode == "train" and step.module.overlap_branches
         batch = W.make_batch(100 + rank, clips_local, args.frames, args.actors, args.points, args.height, args.width, dev)
         log("model + batch ready; %.1f GB allocated" % (torch.cuda.memory_allocated() / 2 ** 30))
         if args.phases and rank == 0 and not ddp:
@@ -539,6 +543,7 @@ def main():
             "config": {"workload": workload, "global_clips": args.clips, "clips_per_gpu": clips_local, "parallelism": "dp%d" % world,
                        "launch": "hip_graph" if step.graph is not None else "eager",
                        "geometry": "prefetched one step ahead (input pipelining)" if args.prefetch_geometry else "in step",
+                       "frozen_rgb": "prefetched one step ahead (under the backward)" if args.prefetch_rgb else "in step",
                        "gradient_exchange": "none" if world == 1 else ("ddp_bucketed" if args.ddp_wrapper else "flat_allreduce"),
                        "trainable_params": W.trainable_parameter_count(step.module)},
             "roofline": roof, "cpu_baseline": cpu, "step_accounting": accounting,

@@ -151,6 +151,13 @@ class ClipModel(nn.Module):
         self.geometry_prefetch = False
         # Microseconds by which the RGB side stream starts after the level-1 FPS kernel has gone out (see forward()); 0 = off
         self.sampling_head_start_us = int(os.environ.get("MGAR_SAMPLING_HEAD_START_US", 20))
+        # Opt-in (bench.py --prefetch-rgb): the same pipelining for the FROZEN RGB branch.  I3D + RoIAlign carry no gradient and
+        # depend on the frames alone, so a step can run them for the NEXT batch on the side stream under its own BACKWARD (an
+        # MFMA-bound pass beside streaming kernels) instead of beside the LiDAR forward.  Every step still runs one I3D pass; only
+        # the order across the step boundary changes.  Off by default, like geometry_prefetch.
+        self.rgb_prefetch = False
+        self._rgb_cur = None        # RoI crops of the batch this step consumes
+        self._rgb_next = None       # crops being computed for the next step (owned by the side stream until finish_prefetch)
         self._geo_cur = None        # geometry of the batch this step consumes (computed during the previous step)
         self._geo_next = None       # geometry being computed for the next step (owned by the side stream until finish_prefetch)
 
@@ -230,6 +237,15 @@ class ClipModel(nn.Module):
         """After the step's BACKWARD (its saved index tensors are the current geometry): join the side stream that computed
         the next batch's geometry and make it the current one -- by copying into the current buffers, so that a captured HIP
         graph keeps reading the same addresses."""
+        if self._rgb_next is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._side_stream)
+            capturing = torch.cuda.is_current_stream_capturing()
+            for a_, b_ in zip(self._rgb_cur, self._rgb_next):
+                if not capturing:
+                    b_.record_stream(main)
+                a_.copy_(b_)
+            self._rgb_next = None
         if self._geo_next is None:
             return
         main = torch.cuda.current_stream()
@@ -279,11 +295,16 @@ class ClipModel(nn.Module):
             finally:
                 shim.BEFORE_SAMPLING_LAUNCH = None
             self._side_stream.wait_event(inputs_ready)
-            if sampling_goes_out:
-                self._side_stream.wait_event(sampling_goes_out[0])
-                L.call("mgar_delay_us", int(self.sampling_head_start_us), self._side_stream.cuda_stream)
-            with torch.cuda.stream(self._side_stream):
-                crops = self.rgb_crops(batch["images"], batch["bboxes"])
+            if self.rgb_prefetch:
+                if self._rgb_cur is None:      # first step: nothing was prefetched -- compute it in line, once
+                    self._rgb_cur = [c.clone() for c in self.rgb_crops(batch["images"], batch["bboxes"])]
+                crops = self._rgb_cur
+            else:
+                if sampling_goes_out:
+                    self._side_stream.wait_event(sampling_goes_out[0])
+                    L.call("mgar_delay_us", int(self.sampling_head_start_us), self._side_stream.cuda_stream)
+                with torch.cuda.stream(self._side_stream):
+                    crops = self.rgb_crops(batch["images"], batch["bboxes"])
             lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], geometry)   # (B*T, A, 512)
             main.wait_stream(self._side_stream)
             if not prefetch:
@@ -301,7 +322,15 @@ class ClipModel(nn.Module):
         # The fusion net works on (A, 512) tokens per scene: launch-bound, not bandwidth-bound.  It runs in fp32 on every
         # configuration (under the bf16 configurations the token producers above are bf16; the tokens are widened here).
         with torch.autocast(device_type=rgb_s.device.type, enabled=False):
-            return self.net.GAR_model(pad(rgb_s.float()), pad(lidar.float()), bb2, batch["bboxes3d"], None, batch["person_id"])
+            out = self.net.GAR_model(pad(rgb_s.float()), pad(lidar.float()), bb2, batch["bboxes3d"], None, batch["person_id"])
+        if batch["images"].is_cuda and self.overlap_branches and self.rgb_prefetch:
+            # the NEXT batch's frozen RGB pass (the caller passes its frames; the benchmark's batches are all the same tensor),
+            # issued where the forward ends: it runs on the side stream under this step's objective and backward
+            main = torch.cuda.current_stream()
+            self._side_stream.wait_event(main.record_event())
+            with torch.cuda.stream(self._side_stream):
+                self._rgb_next = self.rgb_crops(batch.get("next_images", batch["images"]), batch.get("next_bboxes", batch["bboxes"]))
+        return out
 
 
 def _geometry_tensors(geo):

@@ -211,6 +211,49 @@ def test_geometry_prefetch_gives_the_same_step():
     assert abs(float(g._loss) - float(l2)) <= 1e-4 * abs(float(l2)) + 1e-6
 
 
+def test_rgb_prefetch_gives_the_same_step():
+    """ClipModel.rgb_prefetch (bench.py --prefetch-rgb): the frozen I3D + RoIAlign pass computed one step ahead on the side stream,
+    under the previous step's backward, hands the fusion net the same crops as the in-step pass: same loss, same gradients, eager
+    (with a batch that CHANGES between steps: next_images / next_bboxes) and from a captured HIP graph."""
+    from multimodal_gar_amd import workload as W
+
+    def build(prefetch):
+        step = W.TrainStep(4, 2048, DEV, seed=17, manual_allreduce=True)
+        for m in step.module.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+            if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+                m.dropout = 0.0
+        step.module.overlap_branches = True
+        step.module.rgb_prefetch = prefetch
+        return step
+    b1 = W.make_batch(6, 1, 2, 4, 2048, 96, 160, DEV)
+    b2 = W.make_batch(7, 1, 2, 4, 2048, 96, 160, DEV)
+    plain, pre = build(False), build(True)
+    pre.module.load_state_dict(plain.module.state_dict())
+
+    def grads(step):
+        return {n: p.grad.detach().clone() for n, p in step.module.named_parameters() if p.grad is not None}
+    l1 = plain._forward_backward(b1); g1 = grads(plain)
+    l2 = plain._forward_backward(b2); g2 = grads(plain)
+    nxt = dict(next_images=b2["images"], next_bboxes=b2["bboxes"])
+    p1 = pre._forward_backward(dict(b1, **nxt)); q1 = grads(pre)
+    p2 = pre._forward_backward(dict(b2, **nxt)); q2 = grads(pre)      # consumes the crops prefetched during step 1
+    torch.cuda.synchronize()
+    for la, lb, ga, gb in ((l1, p1, g1, q1), (l2, p2, g2, q2)):
+        assert abs(float(la) - float(lb)) <= 1e-5 * abs(float(la)) + 1e-7, (float(la), float(lb))
+        assert set(ga) == set(gb) and len(ga) > 100
+        worst = max(((ga[n] - gb[n]).abs().max().item() / (ga[n].abs().max().item() + 1e-12)) for n in ga)
+        assert worst < 1e-4, worst          # run-to-run noise of the float-atomic kernels only
+    g = build(True)
+    g.module.load_state_dict(plain.module.state_dict())
+    g.capture(b2, warmup=2)
+    g.module.load_state_dict(plain.module.state_dict())
+    g.graph.replay(); g.graph.replay()
+    torch.cuda.synchronize()
+    assert abs(float(g._loss) - float(l2)) <= 1e-4 * abs(float(l2)) + 1e-6
+
+
 def test_c2_full_size_integer_outputs_vs_c_oracle(oracle):
     """at config c2's full per-frame size (16 actors, 8 192 points; two frames of each of its 4 clips) every
     integer output of the LiDAR path -- FPS indices of the four levels, the ball-query rows of both radii per level, the 3-NN
