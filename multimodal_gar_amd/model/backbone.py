@@ -15,6 +15,8 @@ convolution itself instead of materialising a padded copy of the activation with
 """
 from typing import Sequence, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -124,8 +126,8 @@ class Unit3D(nn.Module):
                        L.stream_of(x))
         return y
 
-    gemm_1x1 = True        # 1x1x1 units on the device: a strided-batched GEMM instead of the library convolution
-    wino_kernel = True     # 3x3x3, stride 1 on the device: csrc/conv3d_wino.hip (Winograd F(2,3) along W on the fp32 MFMA)
+    gemm_1x1 = os.environ.get("MGAR_I3D_GEMM_1X1", "1") != "0"        # 1x1x1 units on the device: a strided-batched GEMM instead of the library convolution
+    wino_kernel = os.environ.get("MGAR_I3D_OWN_CONV", "1") != "0"     # 3x3x3, stride 1 on the device: csrc/conv3d_wino.hip (Winograd F(2,3) along W on the fp32 MFMA)
 
     def _k3_conv(self, x):
         """The 3x3x3 / stride-1 units (Conv3d_2c_3x3, every Mixed block's Conv3d_0b_3x3) on csrc/conv3d_wino.hip: "same"
