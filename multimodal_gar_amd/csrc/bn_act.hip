@@ -696,7 +696,7 @@ static int bn_act_bwd_impl(const T *dy, const T *x, int B, int C, int P, const f
     MGAR_REQUIRE(bn_sizes_ok(B, C, P), "bn_act_bwd: bad sizes");
     if ((long long)B * C * P == 0) return MGAR_OK;
     MGAR_REQUIRE(dy && x && mean && invstd && workspace && dx, "bn_act_bwd: null pointer");
-    MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS, "bn_act_bwd: C > 65535 or P too large");
+    MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS * ((P & 3) == 0 ? 4 : 1), "bn_act_bwd: C > 65535 or P too large");
     const int chunk = bn_chunk_bwd(C, (long long)B * P), nchunk = (int)(((long long)B * P + chunk - 1) / chunk);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
@@ -723,7 +723,9 @@ static int bn_act_maxpool_bwd_impl(const T *dpool, const T *pooled, const unsign
     MGAR_REQUIRE(ds.b >= 0 && ds.c >= 1 && ds.m >= 1, "bn_act_maxpool_bwd: bad dpool strides");
     if ((long long)B * C * M == 0) return MGAR_OK;
     MGAR_REQUIRE(dpool && pooled && arg && x && mean && invstd && workspace && dx, "bn_act_maxpool_bwd: null pointer");
-    MGAR_REQUIRE(C <= 65535 && (long long)M * nsample <= 65535LL * BN_THREADS, "bn_act_maxpool_bwd: C > 65535 or M*nsample too large");
+    // (the apply kernel's second grid dimension counts 256-thread blocks of 4 elements when nsample % 4 == 0, of 1 otherwise)
+    MGAR_REQUIRE(C <= 65535 && (long long)M * nsample <= 65535LL * BN_THREADS * ((nsample & 3) == 0 ? 4 : 1),
+                 "bn_act_maxpool_bwd: C > 65535 or M*nsample too large");
     const int chunk = bn_chunk_bwd(C, (long long)B * M), nchunk = (int)(((long long)B * M + chunk - 1) / chunk);
     float *coef = workspace + (size_t)2 * C * nchunk;
     hipStream_t st = (hipStream_t)stream;
@@ -974,7 +976,7 @@ BN_API int mgar_bn_act_bwd_apply(const float *dy, const float *x, int B, int C, 
         if (relu) hipLaunchKernelGGL(bn_bwd_apply_t_kernel<true>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
         else hipLaunchKernelGGL(bn_bwd_apply_t_kernel<false>, grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
     } else {
-        MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS, "bn_act_bwd_apply: C > 65535 or P too large");
+        MGAR_REQUIRE(C <= 65535 && (long long)P <= 65535LL * BN_THREADS * ((P & 3) == 0 ? 4 : 1), "bn_act_bwd_apply: C > 65535 or P too large");
         dim3 grid(B * C, ceil_div(P, BN_THREADS * ((P & 3) == 0 ? 4 : 1)));
         if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, float>), grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
         else hipLaunchKernelGGL((bn_bwd_apply_kernel<false, float>), grid, dim3(BN_THREADS), 0, st, dy, x, C, P, mean, invstd, gamma, beta, coef, dx);
