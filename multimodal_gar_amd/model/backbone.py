@@ -156,11 +156,25 @@ class Unit3D(nn.Module):
             return k3
         if (self.gemm_1x1 and x.is_cuda and x.dim() == 5 and self._kernel_shape == (1, 1, 1) and self._stride == (1, 1, 1)
                 and x.is_contiguous() and self.conv3d.groups == 1 and not torch.is_autocast_enabled()
-                and x.dtype == self.conv3d.weight.dtype):
-            # a 1x1x1 convolution is the GEMM W (C_out, C_in) x (C_in, T*H*W) per sample: one strided-batched library GEMM on the
-            # NCDHW tensor as it lies (MIOpen wraps its NDHWC kernels in two layout transposes and needs a find pass per shape)
-            from ..nn_utils import conv1x1
-            return conv1x1(self.conv3d, x)
+                and x.dtype == self.conv3d.weight.dtype
+                and not (torch.is_grad_enabled() and (x.requires_grad or self.conv3d.weight.requires_grad))):
+            # a 1x1x1 convolution is the GEMM W (C_out, C_in) x (C_in, T*H*W) per sample, on the NCDHW tensor as it lies (MIOpen
+            # wraps its NDHWC kernels in two layout transposes and needs a find pass per shape).  One plain GEMM per sample, not one
+            # strided-batched call: with 5 clips per pass the batched route hung the two-stream graph replay in 2 of 4 runs (4 of 4
+            # with a materialised batch of weights), the per-sample route in 0 of 4 at the same speed -- two library GEMMs of the
+            # batched kind running on two streams at once is the only combination that ever hung (known issues).
+            c = self.conv3d
+            w2 = c.weight.view(c.out_channels, c.in_channels)
+            x3 = x.flatten(2)
+            if os.environ.get("MGAR_1X1_MODE", "mm_loop") == "bmm":          # diagnostics: the batched call
+                y = torch.bmm(w2.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+            else:
+                y = torch.empty((x3.shape[0], c.out_channels, x3.shape[2]), dtype=x.dtype, device=x.device)
+                for n in range(x3.shape[0]):
+                    torch.mm(w2, x3[n], out=y[n])
+            if c.bias is not None:
+                y = y + c.bias.view(1, -1, 1)
+            return y.view(x.shape[0], c.out_channels, *x.shape[2:])
         if all(f == b for f, b in pads):
             return F.conv3d(x, self.conv3d.weight, self.conv3d.bias, self._stride, tuple(f for f, _ in pads))
         return self.conv3d(F.pad(x, _as_fpad(pads)))
