@@ -13,6 +13,9 @@ sys.path.insert(0, ROOT)
 from multimodal_gar_amd import workload as W  # noqa: E402
 
 
+OPS = ("clone", "cat", "copy_", "_to_copy", "contiguous") + tuple(os.environ.get("MGAR_SPY_OPS", "").split(",")) if os.environ.get("MGAR_SPY_OPS") else ("clone", "cat", "copy_", "_to_copy", "contiguous")
+
+
 class Spy(TorchDispatchMode):
     def __init__(self, min_numel):
         super().__init__()
@@ -21,7 +24,7 @@ class Spy(TorchDispatchMode):
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         out = func(*args, **(kwargs or {}))
         name = func.__name__.split(".")[0]
-        if name in ("clone", "cat", "copy_", "_to_copy", "contiguous") and torch.is_tensor(out) and out.numel() >= self.min_numel:
+        if name in OPS and torch.is_tensor(out) and max(out.numel(), max([a.numel() for a in args if torch.is_tensor(a)] or [0])) >= self.min_numel:
             frames = [f for f in traceback.extract_stack() if ROOT in f.filename and "find_copies" not in f.filename][-3:]
             where = " <- ".join("%s:%d" % (os.path.relpath(f.filename, ROOT), f.lineno) for f in reversed(frames))
             self.seen[(name, tuple(out.shape), where)] += 1
