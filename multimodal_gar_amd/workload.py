@@ -149,6 +149,8 @@ class ClipModel(nn.Module):
         # (4.6 ms on 15 workgroups at one clip per rank) off the critical path.  Off by default: the headline numbers are the
         # un-pipelined step.
         self.geometry_prefetch = False
+        # Two-stream step: the LiDAR branch on a third stream instead of the issuing one (see forward())
+        self.branches_off_origin = os.environ.get("MGAR_BRANCHES_OFF_ORIGIN", "1") != "0"
         # Microseconds by which the RGB side stream starts after the level-1 FPS kernel has gone out (see forward()); 0 = off
         self.sampling_head_start_us = int(os.environ.get("MGAR_SAMPLING_HEAD_START_US", 20))
         # Opt-in (bench.py --prefetch-rgb): the same pipelining for the FROZEN RGB branch.  I3D + RoIAlign carry no gradient and
@@ -290,11 +292,28 @@ class ClipModel(nn.Module):
                 # mgar_delay_us): the side stream waits for the moment the sampling kernel goes out, plus a few microseconds.
                 shim.BEFORE_SAMPLING_LAUNCH = lambda: sampling_goes_out.append(torch.cuda.current_stream().record_event())
             try:
-                if not prefetch:
+                if not prefetch and not (self.branches_off_origin and not self.rgb_prefetch):
                     geometry = self.trunk_geometry(batch["points"], self._geo_stream if self.geometry_ahead == "all" else main)   # FPS first
             finally:
                 shim.BEFORE_SAMPLING_LAUNCH = None
             self._side_stream.wait_event(inputs_ready)
+            if self.branches_off_origin and not self.rgb_prefetch and not prefetch:
+                # Both branches away from the stream the step is issued (and captured) on: the RGB branch on the side stream, the
+                # LiDAR branch -- forward here, hence its backward too -- on a third one; the issuing stream only forks and joins.
+                # Measured against the LiDAR branch on the issuing stream (same box, 3 runs each): 177.6-178.4 vs 182.1-182.6 ms
+                # at 8 clips, 95.6 vs 96.9 at 4, 54.2 vs 55.2 at 2, 34.4 both at 1.
+                lst = self._geo_stream
+                with torch.cuda.stream(self._side_stream):     # (issued first: with the LiDAR branch first -- and the RGB branch
+                    crops = self.rgb_crops(batch["images"], batch["bboxes"])   # held back until its sampling kernel is out -- 179.5 ms)
+                with torch.cuda.stream(lst):
+                    lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"], None)
+                main.wait_stream(self._side_stream)
+                main.wait_stream(lst)
+                if not torch.cuda.is_current_stream_capturing():
+                    for c in crops:
+                        c.record_stream(main)
+                    lidar.record_stream(main)
+                return self._fuse(batch, self.rgb_tokens_from_crops(crops), lidar)
             if self.rgb_prefetch:
                 if self._rgb_cur is None:      # first step: nothing was prefetched -- compute it in line, once
                     self._rgb_cur = [c.clone() for c in self.rgb_crops(batch["images"], batch["bboxes"])]
@@ -316,6 +335,10 @@ class ClipModel(nn.Module):
         else:
             rgb = self.rgb_tokens(batch["images"], batch["bboxes"])
             lidar = self.lidar_tokens(batch["points"], batch["bboxes3d"])
+        return self._fuse(batch, rgb, lidar)
+
+    def _fuse(self, batch, rgb, lidar):
+        b, t, a = batch["n_clips"], batch["n_frames"], self.n_actors
         rgb_s = rgb[:, None].expand(b, t, a, rgb.shape[-1]).reshape(b * t, a, -1)   # every frame-scene of a clip
         pad = lambda x: torch.cat([x, x.new_zeros(x.shape[0], 1, x.shape[2])], 1)    # noqa: E731  -> MNP = A + 1
         bb2 = batch["bboxes"][:, None].expand(b, t, a + 1, 4).reshape(b * t, a + 1, 4)
