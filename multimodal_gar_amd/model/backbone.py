@@ -126,7 +126,7 @@ class Unit3D(nn.Module):
                        L.stream_of(x))
         return y
 
-    gemm_1x1 = os.environ.get("MGAR_I3D_GEMM_1X1", "1") != "0"        # 1x1x1 units on the device: a strided-batched GEMM instead of the library convolution
+    gemm_1x1 = os.environ.get("MGAR_I3D_GEMM_1X1", "1") != "0"        # 1x1x1 units on the device: library GEMMs (one per sample) instead of the library convolution
     wino_kernel = os.environ.get("MGAR_I3D_OWN_CONV", "1") != "0"     # 3x3x3, stride 1 on the device: csrc/conv3d_wino.hip (Winograd F(2,3) along W on the fp32 MFMA)
 
     def _k3_conv(self, x):
